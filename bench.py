@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""
+bench.py -- env.step()/s of the vectorised CounterTraffic band-assignment env on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE env.step() of every environment of the batch: one launch of the HIP step
+kernel over 65 536 envs x 4 devices per GPU (BASELINE.json configs[1]).  Actions are
+synthetic (seeded uniform device/duration), generated on the GPU before the timed region;
+every env is reset() at step 0 and every 64 steps so the data-carrying phase stays in play
+(SURVEY.md 8d).  Rank 0 prints ONE JSON line.
+
+  value        whole-job env-steps/s: N_gpus * envs_per_gpu * K / max-over-ranks wall time
+  roofline     HBM bound: algorithmic bytes per launch / average kernel duration (HIP events on
+               the launch stream), against 8 TB/s.  Algorithmic bytes per env-step:
+               B(D) = 17 + 2*(12 + 20*D) + 4*(k_app + k_pop), k_app/k_pop counted by the kernel.
+  cpu_baseline the C oracle (scalar restatement of the reference algorithm, oracle/ct_oracle.c)
+               timed on this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+RESET_EVERY = 64
+
+
+def algorithmic_bytes(D, env_steps, appended, popped):
+    return env_steps * (17 + 2 * (12 + 20 * D)) + 4 * (appended + popped)
+
+
+def cpu_baseline(D, seconds_target=12.0):
+    """The oracle on the host cores, same action distribution, same reset cadence."""
+    import numpy as np
+    from oracle.ct_oracle import CtOracle
+    cores = os.cpu_count() or 1
+    n_env, K = 256 * cores, 64
+    rng = np.random.default_rng(1234)
+    dev = rng.integers(0, D, (K, n_env), dtype=np.int32)
+    dur = rng.integers(0, 20, (K, n_env), dtype=np.int32)
+    orc = CtOracle(n_env, D, nthreads=cores)
+    orc.reset()
+    for k in range(8):
+        orc.step(dev[k], dur[k])                 # warm-up
+    done_steps, t0 = 0, time.perf_counter()
+    while True:
+        orc.reset()
+        for k in range(K):
+            orc.step(dev[k], dur[k])
+        done_steps += K * n_env
+        el = time.perf_counter() - t0
+        if el >= seconds_target:
+            break
+    return {"value": done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d steps per pass (D=%d, reset every pass), repeated for %.1f s on %d threads (OpenMP)"
+                      % (n_env, K, D, el, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--devices", type=int, default=4, help="senders per env (D)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL observation gather at N>1")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gymwipe_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local)
+    dev_t = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev_t)
+
+    N, D, K, W = args.envs, args.devices, args.steps, args.warmup
+    env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, device=dev_t)
+
+    # outputs as three views of ONE 9*N-byte record buffer so that the end-of-step
+    # observation gather is a single RCCL all-gather without a packing kernel
+    rec = torch.empty(9 * N + 16, dtype=torch.uint8, device=dev_t)
+    obs = rec[0:4 * N].view(torch.int32)
+    rew = rec[4 * N:8 * N].view(torch.float32)
+    done = rec[8 * N:9 * N]
+    env._obs, env._rew, env._done = obs, rew, done
+    gathered = torch.empty((world, rec.numel()), dtype=torch.uint8, device=dev_t) if world > 1 else None
+
+    g = torch.Generator(device=dev_t)
+    g.manual_seed(1234 + rank)
+    a_dev = torch.randint(0, D, (W + K, N), dtype=torch.int32, device=dev_t, generator=g)
+    a_dur = torch.randint(0, 20, (W + K, N), dtype=torch.int32, device=dev_t, generator=g)
+    acts = [{"device": a_dev[i], "duration": a_dur[i]} for i in range(W + K)]
+
+    def one(i):
+        if i % RESET_EVERY == 0:
+            env.reset()
+        env.step(acts[i])
+        if gathered is not None and not args.no_gather:
+            dist.all_gather_into_tensor(gathered.view(-1), rec)
+
+    for i in range(W):
+        one(i)
+    torch.cuda.synchronize()
+    s0 = env.stats()
+
+    # ---- timed region: exactly K steps -------------------------------------------------------
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(W, W + K):
+        one(i)
+    ev[1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    s1 = env.stats()
+    env.check()
+
+    # ---- kernel duration: HIP event pair around every launch, same stream, same inputs ---------
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    torch.cuda.synchronize()
+    for j, i in enumerate(range(W, W + K)):
+        if i % RESET_EVERY == 0:
+            env.reset()
+        pairs[j][0].record()
+        env.step(acts[i])
+        pairs[j][1].record()
+    torch.cuda.synchronize()
+    s2 = env.stats()
+    kern_ms = sorted(a.elapsed_time(b) for a, b in pairs)
+    kern_avg_s = sum(kern_ms) / len(kern_ms) * 1e-3
+    stream_s = ev[0].elapsed_time(ev[1]) * 1e-3
+
+    t = torch.tensor([wall], dtype=torch.float64, device=dev_t)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
+    if rank == 0:
+        env_steps = s2["steps"] - s1["steps"]
+        bytes_launch = algorithmic_bytes(D, env_steps, s2["appended"] - s1["appended"],
+                                         s2["popped"] - s1["popped"]) / K
+        achieved = bytes_launch / kern_avg_s
+        value = world * N * K / wall_max
+        out = {
+            "metric": "env.step()/s at 65 536 parallel envs, counter-traffic band-assign",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "CounterTrafficEnv, %d devices, %d vectorised envs per GPU, reset every %d steps"
+                                   % (D, N, RESET_EVERY),
+                       "envs_per_gpu": N, "devices": D, "global_envs": world * N,
+                       "obs_gather": bool(world > 1 and not args.no_gather),
+                       "launches_per_step": 1, "stream_ms_per_step": stream_s / K * 1e3},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "ct_step_kernel", "kernel_avg_us": kern_avg_s * 1e6,
+                         "kernel_median_us": kern_ms[len(kern_ms) // 2] * 1e3,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "algorithmic_bytes_per_env_step": bytes_launch / N},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(D)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+"""
+ctypes binding of the C-ABI (include/gymwipe_amd.h).  Loading fails loudly when the
+HIP library has not been built: there is no Python/CPU fallback for the compute path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libgymwipe_amd.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+ABI_VERSION = 1
+MAX_DEVICES = 32
+MAX_RADIOS = MAX_DEVICES + 1
+QUEUE_CAP = 100
+MAX_NSTATES = 16
+
+OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED, EFIELD = 0, -1, -2, -3, -4, -5, -6
+FLAG_CARRY, FLAG_REFEXC, FLAG_TIE, FLAG_BADACT = 1, 2, 4, 8
+CFG_PER_ENV_STATS = 1
+
+EXPORTS = (
+    "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
+    "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_get_state",
+    "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states",
+)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("hip_device", C.c_int32),
+        ("num_envs", C.c_int64),
+        ("num_devices", C.c_int32),
+        ("flags", C.c_int32),
+        ("pos", (C.c_double * 2) * MAX_RADIOS),
+        ("mult", C.c_int32 * MAX_DEVICES),
+        ("dest", C.c_int32 * MAX_DEVICES),
+        ("slot", C.c_double),
+        ("frequency", C.c_double),
+        ("bandwidth", C.c_double),
+        ("temperature_c", C.c_double),
+        ("bit_rate", C.c_double),
+        ("code_rate", C.c_double),
+        ("max_ber", C.c_double),
+        ("tx_power_dbm", C.c_double),
+        ("counter_interval", C.c_double),
+        ("counter_bound", C.c_int32),
+        ("payload_value", C.c_int32),
+        ("mac_header_bytes", C.c_int32),
+        ("net_header_bytes", C.c_int32),
+        ("duration_factor", C.c_int32),
+        ("max_duration", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("steps", "transmissions", "delivered", "appended",
+                                           "popped", "dropped", "flags_or", "bad_actions")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "gymwipe_amd native error %d: %s" % (code, message))
+        self.code = code
+
+
+def build(force=False, quiet=True):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+            if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(_PKG, "..", "include", "gymwipe_amd.h")]
+    stale = (not os.path.exists(LIB_PATH)
+             or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+    if force or stale:
+        cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it is missing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gymwipe_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C gymwipe_amd/csrc` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+    try:
+        import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.gw_abi_version.argtypes, L.gw_abi_version.restype = [], C.c_int
+    L.gw_last_error.argtypes, L.gw_last_error.restype = [], C.c_char_p
+    L.gw_device_count.argtypes, L.gw_device_count.restype = [C.POINTER(C.c_int)], C.c_int
+    L.gw_config_default.argtypes, L.gw_config_default.restype = [C.POINTER(Config), i64, i32], C.c_int
+    L.gw_create.argtypes, L.gw_create.restype = [C.POINTER(Config), C.POINTER(vp)], C.c_int
+    L.gw_destroy.argtypes, L.gw_destroy.restype = [vp], C.c_int
+    L.gw_reset.argtypes, L.gw_reset.restype = [vp, vp, vp, vp], C.c_int
+    L.gw_step.argtypes, L.gw_step.restype = [vp, vp, vp, vp, vp, vp, vp], C.c_int
+    L.gw_rollout.argtypes, L.gw_rollout.restype = [vp, i32, vp, vp, vp, vp, vp, vp], C.c_int
+    L.gw_received.argtypes, L.gw_received.restype = [vp, vp, vp], C.c_int
+    L.gw_get_state.argtypes, L.gw_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
+    L.gw_stats_read.argtypes, L.gw_stats_read.restype = [vp, C.POINTER(Stats)], C.c_int
+    L.gw_state_bytes.argtypes, L.gw_state_bytes.restype = [vp, C.POINTER(C.c_uint64)], C.c_int
+    L.gw_link_info.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.gw_link_info.restype = C.c_int
+    L.gw_noise_states.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_double)]
+    L.gw_noise_states.restype = C.c_int
+    if L.gw_abi_version() != ABI_VERSION:
+        raise ImportError("gymwipe_amd: ABI mismatch (library %d, python %d); rebuild"
+                          % (L.gw_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise NativeError(rc, (lib().gw_last_error() or b"").decode("utf-8", "replace"))
+
+
+def default_config(num_envs, num_devices):
+    cfg = Config()
+    check(lib().gw_config_default(C.byref(cfg), int(num_envs), int(num_devices)))
+    return cfg

@@ -1,0 +1,395 @@
+// ct_step.hip -- HIP kernels (gfx950) for the vectorised CounterTrafficEnv.step().
+//
+// One launch advances all N environments by one env.step().  The reference walks
+// ~90 SimPy events per step through Python objects (counter_traffic.py:146-158 ->
+// simtools.py:77-88); here the event horizon of a step is enumerated directly per
+// environment in f64, in the reference's exact operation order:
+//
+//   A.1  t_s = t_a + (slot - t_a % slot)                      simtools.py:44-53
+//   A.2  announcement (13 B header + len(str(slots)) B payload); the addressed
+//        sender decides header, then payload                  simple_stack.py:214-286,536-558
+//   A.3  window at the addressed sender: pop + transmit while
+//        (stop - now) > bits/dataRate                         simple_stack.py:397-434
+//   A.4  the RRM decodes each data packet -> interpreter      networking/devices.py:163-168
+//   A.5  t_end = t_r + (slots+1)*slot; counters tick every 1 ms (running f64 sum)
+//        appending `mult` packets of 25+c bytes               counter_traffic.py:53-61
+//   A.6  equal-time events: earlier-inserted first; process initialisation URGENT.
+//
+// No transcendental is evaluated on the device: link powers, BERs and the
+// rx-power residue state machine come from host tables (gw_tables.cpp).
+// Compile with -ffp-contract=off: every f64 result must be the IEEE result of the
+// reference's individual operations.
+#include <hip/hip_runtime.h>
+#include "gw_internal.h"
+
+namespace {
+
+constexpr int kBlock = 64;             // one wavefront per workgroup (v1: thread per env)
+
+struct TxTimes { double t_s, t_h, t_e, stop; };
+
+// simple_stack.py:204 (next slot; a FULL slot when already aligned) +
+// physical.py:244-279 (durations) + simtools.py:112-116 (events fire at now + (t - now))
+__device__ __forceinline__ TxTimes tx_times(double cur, double slot, double hd, double pd)
+{
+    TxTimes x;
+    x.t_s = cur + (slot - fmod(cur, slot));
+    const double dur = hd + pd;
+    x.stop = x.t_s + dur;
+    const double th = x.t_s + hd;
+    x.t_h = (th > x.t_s) ? x.t_s + (th - x.t_s) : x.t_s + 0.0;
+    x.t_e = (x.stop > x.t_s) ? x.t_s + (x.stop - x.t_s) : x.t_s + 0.0;
+    return x;
+}
+
+// simple_stack.py:214-286 with nothing else on the air: header decision at t_h, then the
+// payload error sum counted twice from the same segment start (:180-188,:223-231,:252).
+__device__ __forceinline__ bool receive(double ber, const TxTimes& x, double bit_rate,
+                                        double hdr_bits, double pay_bits, double max_ber,
+                                        uint32_t& flags)
+{
+    double err = 0.0 + ber * (x.t_h - x.t_s) * bit_rate;
+    if (!((rint(err) / hdr_bits) <= max_ber)) return false;
+    const double seg = ber * (x.t_e - x.t_h) * bit_rate;
+    if (!(x.t_e >= x.stop)) flags |= GW_FLAG_REFEXC;      // `not t.completed` -> KeyError in the reference
+    err = (0.0 + seg) + seg;
+    return (rint(err) / pay_bits) <= max_ber;
+}
+
+__device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value))
+{
+    int n = 1;
+    while (v >= 10) { v /= 10; ++n; }
+    return n;
+}
+
+struct Ring {
+    uint32_t* base;
+    int head, len;
+};
+
+struct Tally { uint32_t app, pop, drop, tx, deliv; };
+
+// one counter tick: counter_traffic.py:53-61 -> devices.py:84-86 -> simple_stack.py:463-471
+__device__ __forceinline__ void tick_append(Ring& r, uint32_t size, int mult, Tally& k)
+{
+    for (int m = 0; m < mult; ++m) {
+        if (r.len == GW_QUEUE_CAP) {                      // deque(maxlen=100): drop the oldest
+            r.head = (r.head + 1) & GW_RING_MASK;
+            r.len--;
+            k.drop++;
+        }
+        r.base[(r.head + r.len) & GW_RING_MASK] = size;
+        r.len++;
+        k.app++;
+    }
+}
+
+// all ticks with wake < t (or <= t when inclusive); wake/ctr advance in place
+__device__ __forceinline__ void ticks_until(Ring& r, double& wake, uint32_t& ctr, double t, bool inclusive,
+                                            int mult, uint32_t base_bytes, uint32_t bound, double interval,
+                                            Tally& k, uint32_t& flags)
+{
+    for (;;) {
+        const double w = wake;
+        if (w < t || (inclusive && w == t)) {
+            if (w == t) flags |= GW_FLAG_TIE;
+            tick_append(r, base_bytes + ctr, mult, k);
+            if (ctr < bound) ctr++;
+            wake = w + interval;                          // running sum, not k*dt
+        } else break;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
+    return v;
+}
+
+template <bool PER_ENV_STATS>
+__global__ __launch_bounds__(kBlock) void ct_step_kernel(GwState st,
+                                                        const int32_t* __restrict__ device,
+                                                        const int32_t* __restrict__ duration,
+                                                        int32_t* __restrict__ obs,
+                                                        float* __restrict__ reward,
+                                                        uint8_t* __restrict__ done)
+{
+    const int64_t N = st.N;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const GwDevConst& c = *st.cst;
+    const int D = c.D, R = c.R, S = c.S, RRM = c.D;
+
+    Tally k = {0, 0, 0, 0, 0};
+    uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
+
+    if (e < N) {
+        const int d = device[e];
+        const int du = duration[e];
+        uint32_t fl = st.flags[e];
+        const uint32_t fl_old = fl;
+        uint32_t rvm = st.rvmask[e];
+        int32_t last_abs = st.last_abs[e];
+        uint8_t dn = st.done[e];
+        const int pv = c.payload_value;
+
+        if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
+            // counter_traffic.py:147 asserts; a batched step cannot raise per env: flag + skip
+            fl |= GW_FLAG_BADACT;
+            k_bad = 1;
+            const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
+            obs[e] = latest + c.counter_bound;
+            reward[e] = 0.0f;
+            done[e] = dn;
+        } else {
+            k_steps = 1;
+            const double slot = c.slot, dr = c.data_rate, br = c.bit_rate;
+            const double hd = c.hdr_dur, hdr_bits = c.hdr_bits, max_ber = c.max_ber;
+            const double interval = c.counter_interval;
+            const uint32_t bound = (uint32_t)c.counter_bound;
+            const uint32_t base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
+            const int mh = c.mac_hdr;
+
+            const double t_a = st.now[e];
+            const double wake0 = st.wake[e];
+            const uint32_t ctr0 = st.counter[e];
+            const int slots = du * c.duration_factor;                     // counter_traffic.py:149
+
+            // ---- A.1 / A.2: announcement ---------------------------------------------
+            const int L = ndigits(slots);
+            const double pd_a = (double)(L * 8) / dr;
+            const TxTimes an = tx_times(t_a, slot, hd, pd_a);
+            k.tx++;
+            uint8_t s_d = st.rxs[(int64_t)d * N + e];
+            const uint8_t s_d_old = s_d;
+            s_d = st.trans[((int64_t)d * R + RRM) * S + s_d];
+            const double ber_a = st.ber[((int64_t)d * R + RRM) * S + s_d];
+            const bool granted = receive(ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, max_ber, fl);
+            const double t_r = an.t_e;
+            const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
+
+            // ---- A.3: window at sender d -----------------------------------------------
+            double wake_d = wake0;
+            uint32_t ctr_d = ctr0;
+            const uint16_t hl_d = st.qhl[(int64_t)d * N + e];
+            Ring rd;
+            rd.base = st.ring + (((int64_t)e * D + d) << 7);
+            rd.head = hl_d & 0xff;
+            rd.len = hl_d >> 8;
+            const int mult_d = c.mult[d];
+            int n_data = 0;
+            uint8_t s_r = 0;
+            bool s_r_loaded = false;
+            uint8_t s_r_old = 0;
+
+            if (granted) {
+                const double total = (double)slots * slot;               // simple_stack.py:400
+                const double stopw = t_r + total;                        // :401 (== timeout time :406)
+                double cur = t_r;
+                // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
+                ticks_until(rd, wake_d, ctr_d, cur, false, mult_d, base_bytes, bound, interval, k, fl);
+                for (;;) {
+                    if (rd.len == 0) {                                    // :409-416
+                        const double w = wake_d;
+                        if (w < stopw) {
+                            cur = w;
+                            tick_append(rd, base_bytes + ctr_d, mult_d, k);
+                            if (ctr_d < bound) ctr_d++;
+                            wake_d = w + interval;
+                        } else break;
+                    }
+                    const uint32_t s = rd.base[rd.head];
+                    const double need = (double)(s * 8u) / dr;           // messages.py:67-75
+                    if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
+                    rd.head = (rd.head + 1) & GW_RING_MASK;               // :425
+                    rd.len--;
+                    k.pop++;
+                    const int pay = (int)s - mh;
+                    const TxTimes x = tx_times(cur, slot, hd, (double)(pay * 8) / dr);
+                    k.tx++;
+                    n_data++;
+                    if (!s_r_loaded) { s_r = st.rxs[(int64_t)RRM * N + e]; s_r_old = s_r; s_r_loaded = true; }
+                    s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
+                    const double ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
+                    const bool ok = receive(ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, max_ber, fl);
+                    if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
+                        k.deliv++;
+                        rvm |= (1u << d);
+                        if (pv == c.counter_bound) dn = 1;
+                    }
+                    if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
+                    // ticks are older events than the MAC's resume at t_e: they go first
+                    ticks_until(rd, wake_d, ctr_d, x.t_e, true, mult_d, base_bytes, bound, interval, k, fl);
+                    cur = x.t_e;
+                    if (!(cur < stopw)) break;                            // window timeout already processed
+                }
+            }
+
+            // ---- A.5: remaining ticks up to the end of the step ----------------------------
+            ticks_until(rd, wake_d, ctr_d, t_end, true, mult_d, base_bytes, bound, interval, k, fl);
+            st.qhl[(int64_t)d * N + e] = (uint16_t)(rd.head | (rd.len << 8));
+            for (int i = 0; i < D; ++i) {
+                if (i == d) continue;
+                const uint16_t hl = st.qhl[(int64_t)i * N + e];
+                Ring ri;
+                ri.base = st.ring + (((int64_t)e * D + i) << 7);
+                ri.head = hl & 0xff;
+                ri.len = hl >> 8;
+                double w = wake0;
+                uint32_t ct = ctr0;
+                ticks_until(ri, w, ct, t_end, true, c.mult[i], base_bytes, bound, interval, k, fl);
+                st.qhl[(int64_t)i * N + e] = (uint16_t)(ri.head | (ri.len << 8));
+            }
+
+            // ---- rx-power state of every radio (simple_stack.py:130-157) ---------------------
+            if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
+            if (s_r_loaded && s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
+            for (int j = 0; j < D; ++j) {
+                if (j == d) continue;
+                uint8_t s = st.rxs[(int64_t)j * N + e];
+                const uint8_t s0 = s;
+                s = st.trans[((int64_t)j * R + RRM) * S + s];
+                for (int n = 0; n < n_data; ++n) {
+                    const uint8_t s2 = st.trans[((int64_t)j * R + d) * S + s];
+                    if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
+                    s = s2;
+                }
+                if (s != s0) st.rxs[(int64_t)j * N + e] = s;
+            }
+
+            // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -------
+            const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
+            const int32_t abs_d = latest < 0 ? -latest : latest;
+            int32_t r = last_abs - abs_d;
+            last_abs = abs_d;
+            r = r > 10 ? 10 : (r < -10 ? -10 : r);
+            obs[e] = latest + c.counter_bound;
+            reward[e] = (float)r;
+            done[e] = dn;
+
+            st.now[e] = t_end;
+            st.wake[e] = wake_d;
+            st.counter[e] = ctr_d;
+            st.rvmask[e] = rvm;
+            st.last_abs[e] = last_abs;
+            st.done[e] = dn;
+            if (PER_ENV_STATS) {
+                st.pe_stats[0 * N + e] += k.tx;
+                st.pe_stats[1 * N + e] += k.deliv;
+                st.pe_stats[2 * N + e] += k.app;
+                st.pe_stats[3 * N + e] += k.pop;
+                st.pe_stats[4 * N + e] += k.drop;
+            }
+        }
+        if (fl != fl_old) st.flags[e] = fl;
+        fl_new = fl;
+    }
+
+    // ---- totals: one atomic per wave and counter ---------------------------------------------
+    const uint32_t t_tx = wave_sum(k.tx), t_dl = wave_sum(k.deliv), t_ap = wave_sum(k.app);
+    const uint32_t t_po = wave_sum(k.pop), t_dr = wave_sum(k.drop), t_bad = wave_sum(k_bad);
+    const uint32_t t_st = wave_sum(k_steps), t_fl = wave_or(fl_new);
+    if (threadIdx.x == 0) {
+        atomicAdd(&st.totals[GW_T_STEPS], (unsigned long long)t_st);
+        atomicAdd(&st.totals[GW_T_TX], (unsigned long long)t_tx);
+        atomicAdd(&st.totals[GW_T_APP], (unsigned long long)t_ap);
+        if (t_dl) atomicAdd(&st.totals[GW_T_DELIV], (unsigned long long)t_dl);
+        if (t_po) atomicAdd(&st.totals[GW_T_POP], (unsigned long long)t_po);
+        if (t_dr) atomicAdd(&st.totals[GW_T_DROP], (unsigned long long)t_dr);
+        if (t_bad) atomicAdd(&st.totals[GW_T_BAD], (unsigned long long)t_bad);
+        if (t_fl) atomicOr(&st.totals[GW_T_FLAGS], (unsigned long long)t_fl);
+    }
+}
+
+// fresh env: counters 1 (counter_traffic.py:48), first tick at t=0, all radios at thermal noise
+__global__ void ct_init_kernel(GwState st)
+{
+    const int64_t N = st.N;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int D = st.cst->D, R = st.cst->R;
+    st.now[e] = 0.0;
+    st.wake[e] = 0.0;
+    st.counter[e] = 1u;
+    st.rvmask[e] = 0u;
+    st.last_abs[e] = 0;
+    st.done[e] = 0;
+    st.flags[e] = 0u;
+    for (int i = 0; i < D; ++i) st.qhl[(int64_t)i * N + e] = 0;
+    for (int r = 0; r < R; ++r) st.rxs[(int64_t)r * N + e] = 0;
+    if (st.pe_stats) for (int s = 0; s < 5; ++s) st.pe_stats[(int64_t)s * N + e] = 0ull;
+}
+
+// counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound
+__global__ void ct_reset_kernel(GwState st, const uint8_t* __restrict__ mask, int32_t* __restrict__ obs)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= st.N) return;
+    if (!mask || mask[e]) {
+        st.counter[e] = 0u;
+        st.rvmask[e] = 0u;
+        st.last_abs[e] = 0;
+        st.done[e] = 0;
+    }
+    if (obs) {
+        const uint32_t rvm = st.rvmask[e];
+        obs[e] = st.cst->payload_value * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u)) + st.cst->counter_bound;
+    }
+}
+
+__global__ void ct_received_kernel(GwState st, int32_t* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = st.cst->D;
+    if (idx >= st.N * D) return;
+    const int64_t e = idx / D;
+    const int i = (int)(idx - e * D);
+    out[idx] = ((st.rvmask[e] >> i) & 1u) ? st.cst->payload_value : 0;
+}
+
+inline int check_launch()
+{
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
+} // namespace
+
+int gw_launch_init(const GwState& st, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + 255) / 256);
+    hipLaunchKernelGGL(ct_init_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st);
+    return check_launch();
+}
+
+int gw_launch_reset(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + 255) / 256);
+    hipLaunchKernelGGL(ct_reset_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, mask, obs);
+    return check_launch();
+}
+
+int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* duration,
+                   int32_t* obs, float* reward, uint8_t* done, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + kBlock - 1) / kBlock);
+    if (st.pe_stats)
+        hipLaunchKernelGGL(ct_step_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                           st, device, duration, obs, reward, done);
+    else
+        hipLaunchKernelGGL(ct_step_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                           st, device, duration, obs, reward, done);
+    return check_launch();
+}
+
+int gw_launch_received(const GwState& st, int32_t* out, void* stream)
+{
+    const int64_t total = st.N * (int64_t)st.D;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(ct_received_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, out);
+    return check_launch();
+}

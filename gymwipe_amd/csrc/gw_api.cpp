@@ -1,0 +1,405 @@
+// gw_api.cpp -- implementation of the C-ABI declared in include/gymwipe_amd.h.
+// Host side only: configuration, table upload, HBM allocation, launches, readers.
+// There is deliberately no CPU fallback: without a HIP device every compute
+// entry point fails with GW_ENODEVICE.
+#include "gw_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail(GW_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e));            \
+    } while (0)
+
+} // namespace
+
+struct gw_env {
+    gw_config    cfg;
+    GwHostTables tab;
+    GwDevConst   cst_host;
+    GwState      st;          // device pointers
+    void*        blocks[32];  // every hipMalloc'd block, for gw_destroy
+    int          nblocks;
+    uint64_t     bytes;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(gw_env* env, T** out, size_t count)
+{
+    void* p = nullptr;
+    const size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(GW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    env->blocks[env->nblocks++] = p;
+    env->bytes += bytes;
+    *out = (T*)p;
+    return GW_OK;
+}
+
+int select_device(const gw_env* env)
+{
+    HIP_TRY(hipSetDevice(env->cfg.hip_device));
+    return GW_OK;
+}
+
+int validate(const gw_config& c)
+{
+    if (c.abi_version != GW_ABI_VERSION) return fail(GW_EINVAL, "abi_version %d != %d", c.abi_version, GW_ABI_VERSION);
+    if (c.num_envs <= 0) return fail(GW_EINVAL, "num_envs must be positive");
+    if (c.num_devices < 2 || c.num_devices > GW_MAX_DEVICES)
+        return fail(GW_EINVAL, "num_devices must be in [2, %d] (observation uses senders 0 and 1)", GW_MAX_DEVICES);
+    for (int i = 0; i < c.num_devices; ++i) {
+        if (c.mult[i] < 1 || c.mult[i] > GW_QUEUE_CAP) return fail(GW_EINVAL, "mult[%d] out of range", i);
+        if (c.dest[i] < 0 || c.dest[i] >= c.num_devices) return fail(GW_EINVAL, "dest[%d] out of range", i);
+    }
+    if (!(c.slot > 0) || !(c.bit_rate > 0) || !(c.code_rate > 0 && c.code_rate <= 1) || !(c.counter_interval > 0))
+        return fail(GW_EINVAL, "slot, bit_rate, code_rate and counter_interval must be positive");
+    if (c.mac_header_bytes < 1 || c.net_header_bytes < 0 || c.counter_bound < 1 || c.duration_factor < 1 || c.max_duration < 1)
+        return fail(GW_EINVAL, "header sizes / bounds out of range");
+    if ((int64_t)c.max_duration * c.duration_factor > 100000000)
+        return fail(GW_EINVAL, "max_duration*duration_factor too large");
+    return GW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int gw_abi_version(void) { return GW_ABI_VERSION; }
+
+const char* gw_last_error(void) { return g_err; }
+
+int gw_device_count(int* count)
+{
+    if (!count) return fail(GW_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(GW_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return GW_OK;
+}
+
+int gw_config_default(gw_config* c, int64_t num_envs, int32_t D)
+{
+    if (!c) return fail(GW_EINVAL, "cfg is NULL");
+    if (D < 2 || D > GW_MAX_DEVICES) return fail(GW_EINVAL, "num_devices must be in [2, %d]", GW_MAX_DEVICES);
+    memset(c, 0, sizeof *c);
+    c->abi_version = GW_ABI_VERSION;
+    c->hip_device = 0;
+    c->num_envs = num_envs;
+    c->num_devices = D;
+    if (D == 2) {                                   // counter_traffic.py:124-127
+        c->pos[0][0] = 0.0; c->pos[0][1] = 2.0;
+        c->pos[1][0] = 0.0; c->pos[1][1] = -2.0;
+    } else {                                        // circle of radius 2 m around the RRM
+        for (int i = 0; i < D; ++i) {
+            const double ang = M_PI / 2 - 2 * M_PI * i / D;
+            c->pos[i][0] = 2.0 * cos(ang);
+            c->pos[i][1] = 2.0 * sin(ang);
+        }
+    }
+    c->pos[D][0] = 0.0; c->pos[D][1] = 0.0;         // counter_traffic.py:133
+    for (int i = 0; i < D; ++i) {
+        c->mult[i] = (i % 2 == 0) ? 1 : 3;          // counter_traffic.py:125-126
+        c->dest[i] = (i + 1) % D;                   // :129-130
+    }
+    c->slot = 1e-6;                                 // simple_stack.py:27
+    c->frequency = 2.4e9;                           // physical.py:298
+    c->bandwidth = 22e6;
+    c->temperature_c = 20.0;                        // simple_stack.py:57
+    c->bit_rate = 133.33333e3;                      // physical.py:196
+    c->code_rate = 0.75;                            // physical.py:192
+    c->max_ber = 0.25;                              // physical.py:160-185 for 3/4
+    c->tx_power_dbm = 0.0;                          // simple_stack.py:364,521
+    c->counter_interval = 0.001;                    // counter_traffic.py:31
+    c->counter_bound = 65536;                       // :35
+    c->payload_value = 2;                           // :57 (swapped constructor arguments)
+    c->mac_header_bytes = 13;                       // messages.py:154
+    c->net_header_bytes = 12;                       // messages.py:180
+    c->duration_factor = 1000;                      // envs/core.py:27
+    c->max_duration = 20;                           // envs/core.py:25
+    return GW_OK;
+}
+
+int gw_create(const gw_config* cfg, gw_env** out)
+{
+    if (!cfg || !out) return fail(GW_EINVAL, "cfg/out is NULL");
+    *out = nullptr;
+    int rc = validate(*cfg);
+    if (rc) return rc;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GW_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (cfg->hip_device < 0 || cfg->hip_device >= ndev)
+        return fail(GW_EINVAL, "hip_device %d out of range (have %d)", cfg->hip_device, ndev);
+
+    gw_env* env = new (std::nothrow) gw_env();
+    if (!env) return fail(GW_ENOMEM, "out of host memory");
+    memset(env, 0, sizeof *env);
+    env->cfg = *cfg;
+
+    char msg[256] = "";
+    rc = gw_build_tables(env->cfg, env->tab, msg, sizeof msg);
+    if (rc) { delete env; return fail(rc, "%s", msg); }
+
+    if ((rc = select_device(env))) { delete env; return rc; }
+
+    const int D = cfg->num_devices, R = D + 1;
+    const int64_t N = cfg->num_envs;
+    GwDevConst& k = env->cst_host;
+    k.D = D; k.R = R; k.S = GW_MAX_NSTATES;
+    k.counter_bound = cfg->counter_bound; k.payload_value = cfg->payload_value;
+    k.mac_hdr = cfg->mac_header_bytes; k.net_hdr = cfg->net_header_bytes;
+    k.duration_factor = cfg->duration_factor; k.max_duration = cfg->max_duration;
+    for (int i = 0; i < D; ++i) k.mult[i] = cfg->mult[i];
+    k.slot = cfg->slot; k.data_rate = env->tab.data_rate; k.bit_rate = cfg->bit_rate;
+    k.coded_factor = env->tab.coded_factor; k.max_ber = cfg->max_ber; k.counter_interval = cfg->counter_interval;
+    {
+        volatile double hb = (double)(cfg->mac_header_bytes * 8);
+        k.hdr_dur = hb / env->tab.data_rate;        // physical.py:244
+        k.hdr_bits = hb * env->tab.coded_factor;    // physical.py:259
+    }
+
+    GwState& st = env->st;
+    st.N = N; st.D = D; st.R = R;
+    GwDevConst* d_cst = nullptr; uint8_t* d_trans = nullptr; double* d_ber = nullptr;
+    const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
+#define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
+    TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
+    TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
+    TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
+    TRY_ALLOC(st.rxs, N * R);  TRY_ALLOC(st.flags, N);
+    if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
+    TRY_ALLOC(st.totals, GW_T_COUNT);
+    TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount);  TRY_ALLOC(d_ber, tcount);
+#undef TRY_ALLOC
+    st.cst = d_cst; st.trans = d_trans; st.ber = d_ber;
+
+#define HIP_TRY_D(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rc = fail(GW_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); gw_destroy(env); return rc; } } while (0)
+    HIP_TRY_D(hipMemcpy(d_cst, &k, sizeof k, hipMemcpyHostToDevice));
+    HIP_TRY_D(hipMemcpy(d_trans, env->tab.trans, tcount * sizeof(uint8_t), hipMemcpyHostToDevice));
+    HIP_TRY_D(hipMemcpy(d_ber, env->tab.ber, tcount * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_D(hipMemset(st.totals, 0, GW_T_COUNT * sizeof(unsigned long long)));
+    HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
+    rc = gw_launch_init(st, nullptr);
+    if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
+    HIP_TRY_D(hipDeviceSynchronize());
+#undef HIP_TRY_D
+    *out = env;
+    return GW_OK;
+}
+
+int gw_destroy(gw_env* env)
+{
+    if (!env) return GW_OK;
+    (void)hipSetDevice(env->cfg.hip_device);
+    for (int i = 0; i < env->nblocks; ++i) (void)hipFree(env->blocks[i]);
+    delete env;
+    return GW_OK;
+}
+
+int gw_reset(gw_env* env, const uint8_t* mask_dev, int32_t* obs_dev, void* stream)
+{
+    if (!env) return fail(GW_EINVAL, "env is NULL");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_reset(env->st, mask_dev, obs_dev, stream)) return fail(GW_EHIP, "reset kernel launch failed");
+    return GW_OK;
+}
+
+int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
+            int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream)
+{
+    if (!env) return fail(GW_EINVAL, "env is NULL");
+    if (!device_dev || !duration_dev || !obs_dev || !reward_dev || !done_dev)
+        return fail(GW_EINVAL, "gw_step: NULL device pointer");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_step(env->st, device_dev, duration_dev, obs_dev, reward_dev, done_dev, stream))
+        return fail(GW_EHIP, "step kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return GW_OK;
+}
+
+int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int32_t* duration_dev,
+               int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream)
+{
+    if (!env) return fail(GW_EINVAL, "env is NULL");
+    if (steps < 0) return fail(GW_EINVAL, "steps < 0");
+    if (!device_dev || !duration_dev || !obs_dev || !reward_dev || !done_dev)
+        return fail(GW_EINVAL, "gw_rollout: NULL device pointer");
+    int rc = select_device(env);
+    if (rc) return rc;
+    const int64_t N = env->st.N;
+    for (int32_t s = 0; s < steps; ++s) {
+        const int64_t o = (int64_t)s * N;
+        if (gw_launch_step(env->st, device_dev + o, duration_dev + o, obs_dev + o, reward_dev + o, done_dev + o, stream))
+            return fail(GW_EHIP, "step kernel launch failed at step %d", s);
+    }
+    return GW_OK;
+}
+
+int gw_received(gw_env* env, int32_t* out_dev, void* stream)
+{
+    if (!env || !out_dev) return fail(GW_EINVAL, "env/out is NULL");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_received(env->st, out_dev, stream)) return fail(GW_EHIP, "received kernel launch failed");
+    return GW_OK;
+}
+
+int gw_stats_read(gw_env* env, gw_stats* out)
+{
+    if (!env || !out) return fail(GW_EINVAL, "env/out is NULL");
+    int rc = select_device(env);
+    if (rc) return rc;
+    unsigned long long t[GW_T_COUNT];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(t, env->st.totals, sizeof t, hipMemcpyDeviceToHost));
+    out->steps = t[GW_T_STEPS]; out->transmissions = t[GW_T_TX]; out->delivered = t[GW_T_DELIV];
+    out->appended = t[GW_T_APP]; out->popped = t[GW_T_POP]; out->dropped = t[GW_T_DROP];
+    out->flags_or = t[GW_T_FLAGS]; out->bad_actions = t[GW_T_BAD];
+    return GW_OK;
+}
+
+int gw_state_bytes(gw_env* env, uint64_t* bytes)
+{
+    if (!env || !bytes) return fail(GW_EINVAL, "env/bytes is NULL");
+    *bytes = env->bytes;
+    return GW_OK;
+}
+
+int gw_link_info(gw_env* env, int32_t from, int32_t to, double* att, double* prx)
+{
+    if (!env) return fail(GW_EINVAL, "env is NULL");
+    const int R = env->tab.R;
+    if (from < 0 || from >= R || to < 0 || to >= R || from == to) return fail(GW_EINVAL, "radio index out of range");
+    if (att) *att = env->tab.att[from][to];
+    if (prx) *prx = env->tab.prx[from][to];
+    return GW_OK;
+}
+
+int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values)
+{
+    if (!env || !count) return fail(GW_EINVAL, "env/count is NULL");
+    if (radio < 0 || radio >= env->tab.R) return fail(GW_EINVAL, "radio index out of range");
+    *count = env->tab.nstates[radio];
+    if (values) for (int i = 0; i < GW_MAX_NSTATES; ++i) values[i] = i < *count ? env->tab.state_val[radio][i] : 0.0;
+    return GW_OK;
+}
+
+int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
+{
+    if (!env || !field || !dst) return fail(GW_EINVAL, "env/field/dst is NULL");
+    int rc = select_device(env);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const GwState& st = env->st;
+    const int64_t N = st.N;
+    const int D = st.D, R = st.R;
+
+#define NEED(count, type) do { if (bytes != (size_t)(count) * sizeof(type)) \
+        return fail(GW_EFIELD, "field %s needs %zu bytes, got %zu", field, (size_t)(count) * sizeof(type), bytes); } while (0)
+
+    if (!strcmp(field, "now")) { NEED(N, double); HIP_TRY(hipMemcpy(dst, st.now, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
+    if (!strcmp(field, "last_abs")) { NEED(N, int32_t); HIP_TRY(hipMemcpy(dst, st.last_abs, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
+    if (!strcmp(field, "flags")) { NEED(N, uint32_t); HIP_TRY(hipMemcpy(dst, st.flags, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
+    if (!strcmp(field, "wake")) {
+        NEED(N * D, double);
+        std::vector<double> w(N);
+        HIP_TRY(hipMemcpy(w.data(), st.wake, N * sizeof(double), hipMemcpyDeviceToHost));
+        double* o = (double*)dst;
+        for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = w[e];
+        return GW_OK;
+    }
+    if (!strcmp(field, "counter")) {
+        NEED(N * D, uint32_t);
+        std::vector<uint32_t> c(N);
+        HIP_TRY(hipMemcpy(c.data(), st.counter, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t* o = (uint32_t*)dst;
+        for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = c[e];
+        return GW_OK;
+    }
+    if (!strcmp(field, "received") || !strcmp(field, "latest_diff")) {
+        std::vector<uint32_t> m(N);
+        HIP_TRY(hipMemcpy(m.data(), st.rvmask, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const int pv = env->cfg.payload_value;
+        if (field[0] == 'r') {
+            NEED(N * D, int32_t);
+            int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ((m[e] >> i) & 1u) ? pv : 0;
+        } else {
+            NEED(N, int32_t);
+            int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) o[e] = pv * ((int)(m[e] & 1u) - (int)((m[e] >> 1) & 1u));
+        }
+        return GW_OK;
+    }
+    if (!strcmp(field, "qlen") || !strcmp(field, "queue")) {
+        std::vector<uint16_t> hl((size_t)N * D);
+        HIP_TRY(hipMemcpy(hl.data(), st.qhl, hl.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        if (field[1] == 'l') {
+            NEED(N * D, int32_t);
+            int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = hl[(size_t)i * N + e] >> 8;
+            return GW_OK;
+        }
+        NEED(N * D * GW_QUEUE_CAP, uint32_t);
+        std::vector<uint32_t> ring((size_t)N * D * GW_RING_PHYS);
+        HIP_TRY(hipMemcpy(ring.data(), st.ring, ring.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t* o = (uint32_t*)dst;
+        for (int64_t e = 0; e < N; ++e)
+            for (int i = 0; i < D; ++i) {
+                const int head = hl[(size_t)i * N + e] & 0xff, len = hl[(size_t)i * N + e] >> 8;
+                const uint32_t* r = ring.data() + ((size_t)e * D + i) * GW_RING_PHYS;
+                uint32_t* q = o + ((size_t)e * D + i) * GW_QUEUE_CAP;
+                for (int s = 0; s < GW_QUEUE_CAP; ++s) q[s] = s < len ? r[(head + s) & GW_RING_MASK] : 0u;
+            }
+        return GW_OK;
+    }
+    if (!strcmp(field, "rx_power")) {
+        NEED(N * R, double);
+        std::vector<uint8_t> s((size_t)N * R);
+        HIP_TRY(hipMemcpy(s.data(), st.rxs, s.size(), hipMemcpyDeviceToHost));
+        double* o = (double*)dst;
+        for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = env->tab.state_val[r][s[(size_t)r * N + e]];
+        return GW_OK;
+    }
+    static const char* pe[5] = {"n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped"};
+    for (int k = 0; k < 5; ++k)
+        if (!strcmp(field, pe[k])) {
+            if (!st.pe_stats) return fail(GW_EFIELD, "field %s needs GW_CFG_PER_ENV_STATS", field);
+            NEED(N, uint64_t);
+            HIP_TRY(hipMemcpy(dst, st.pe_stats + (size_t)k * N, bytes, hipMemcpyDeviceToHost));
+            return GW_OK;
+        }
+#undef NEED
+    return fail(GW_EFIELD, "unknown field %s", field);
+}
+
+} // extern "C"

@@ -1,0 +1,68 @@
+// gw_internal.h -- shared between the host side (gw_api.cpp, gw_tables.cpp) and the
+// HIP kernels (ct_step.hip).  Not part of the public C-ABI.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gymwipe_amd.h"
+
+#define GW_RING_PHYS      128          // physical ring slots per (env, sender); logical capacity GW_QUEUE_CAP
+#define GW_RING_MASK      (GW_RING_PHYS - 1)
+#define GW_MAX_NSTATES    16           // rx-power (noise residue) states per radio, see gw_tables.cpp
+
+// Constants the kernels need, resident in device global memory (read through
+// the scalar cache: every field is wave-uniform).
+struct GwDevConst {
+    int32_t D, R, S;                    // senders, radios (D+1), states per radio (GW_MAX_NSTATES)
+    int32_t counter_bound, payload_value, mac_hdr, net_hdr, duration_factor, max_duration;
+    int32_t mult[GW_MAX_DEVICES];
+    double  slot, data_rate, bit_rate, coded_factor, max_ber, counter_interval;
+    double  hdr_dur;                    // (mac_hdr*8)/data_rate
+    double  hdr_bits;                   // (mac_hdr*8)*coded_factor
+};
+
+// Per-handle device state (structure of arrays; N = num_envs, D senders, R = D+1 radios).
+struct GwState {
+    int64_t   N;
+    int32_t   D, R;     // host-side copies of the constants (launch sizing)
+    double*   now;        // [N]        simulated time (SimMan.now)
+    double*   wake;       // [N]        next counter tick (all senders tick in lock-step)
+    uint32_t* counter;    // [N]        sender.counter (identical for all senders of an env)
+    uint16_t* qhl;        // [D][N]     ring head (low byte) | length (high byte)
+    uint32_t* ring;       // [N][D][GW_RING_PHYS]  packet byte sizes (SimpleMac._packetQueue)
+    uint32_t* rvmask;     // [N]        bit i set <=> receivedValues[i] == payload_value
+    int32_t*  last_abs;   // [N]        interpreter._lastAbsDifference
+    uint8_t*  done;       // [N]        interpreter._done
+    uint8_t*  rxs;        // [R][N]     rx-power state index per radio (stands for phy._receivedPower)
+    uint32_t* flags;      // [N]        sticky GW_FLAG_* bits
+    uint64_t* pe_stats;   // [5][N] or nullptr: n_tx, n_delivered, n_appended, n_popped, n_dropped
+    unsigned long long* totals;  // [8] steps, tx, delivered, appended, popped, dropped, flags_or, bad_actions
+    const GwDevConst* cst;
+    const uint8_t*    trans;     // [R to][R from][S]  state after hearing `from`
+    const double*     ber;       // [R to][R from][S]  BER at `to` while hearing `from`, indexed by the NEW state
+};
+
+enum { GW_T_STEPS = 0, GW_T_TX, GW_T_DELIV, GW_T_APP, GW_T_POP, GW_T_DROP, GW_T_FLAGS, GW_T_BAD, GW_T_COUNT };
+
+// Host-side link tables (gw_tables.cpp)
+struct GwHostTables {
+    int D, R;
+    double att[GW_MAX_RADIOS][GW_MAX_RADIOS];        // dB
+    double prx[GW_MAX_RADIOS][GW_MAX_RADIOS];        // mW, [from][to]
+    double thermal;                                   // mW
+    double data_rate, coded_factor;
+    int    nstates[GW_MAX_RADIOS];
+    double state_val[GW_MAX_RADIOS][GW_MAX_NSTATES];  // mW; index 0 = thermal
+    // flattened [to][from][s]
+    uint8_t trans[GW_MAX_RADIOS * GW_MAX_RADIOS * GW_MAX_NSTATES];
+    double  ber[GW_MAX_RADIOS * GW_MAX_RADIOS * GW_MAX_NSTATES];
+};
+
+// returns GW_OK or an error code; msg receives a description on failure
+int gw_build_tables(const gw_config& cfg, GwHostTables& out, char* msg, size_t msglen);
+
+// kernel launchers (ct_step.hip); stream is a hipStream_t
+int gw_launch_init(const GwState& st, void* stream);
+int gw_launch_reset(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
+int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* duration,
+                   int32_t* obs, float* reward, uint8_t* done, void* stream);
+int gw_launch_received(const GwState& st, int32_t* out, void* stream);

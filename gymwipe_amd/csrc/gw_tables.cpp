@@ -1,0 +1,110 @@
+// gw_tables.cpp -- host-side static link tables for the vectorised CounterTraffic step.
+//
+// Geometry is static in the band-assignment envs, so everything that needs a
+// transcendental is evaluated ONCE per handle here, on the host, through the same
+// glibc libm entry points CPython uses (log10 / pow / sqrt) -- bit-identical to the
+// reference's Python expressions -- and the kernels only do +,-,*,/,fmod,rint in f64.
+//
+// The one piece of per-env floating-point state the PHY model carries is
+// phy._receivedPower (simple_stack.py:80-86): thermal noise plus the residue of
+// every (+p, -p) pair it has seen.  With at most one transmission on the air
+// (contention-free MAC), hearing sender `i` maps the resting value a to
+//      g(a, p) = fl(fl(a + p) - p),
+// and that SAME value is the noise term during the reception (noise = rx - p,
+// simple_stack.py:166-167).  g lands on the ulp grid of p, so the set of reachable
+// resting values per radio is tiny (<= 8 for 32 senders on the default circle).  We
+// enumerate that closure here and let the kernels carry a one-byte state index per
+// radio instead of an f64, with the BER of every (listener, talker, state) tabulated.
+// This is exact, not an approximation: tests compare the reconstructed f64 with the
+// oracle's running value bit for bit.
+#include "gw_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+// devices/core.py:88-95 (x**2 is pow(x, 2.0) in CPython) + attenuation_models.py:28-36
+double fspl_db(const gw_config& c, int a, int b)
+{
+    const double ax = c.pos[a][0], ay = c.pos[a][1], bx = c.pos[b][0], by = c.pos[b][1];
+    if (ax == bx && ay == by) return 0.0;          // co-located: the model keeps attenuation 0
+    const double dist = sqrt(pow(ax - bx, 2.0) + pow(ay - by, 2.0));
+    return 20 * log10(dist) + 20 * log10(c.frequency) - 147.55;
+}
+
+// physical.py:25-58 (Eb/N0, Q approximation), :82-98 (dBm helpers), :208-212 (BPSK)
+double ber_bpsk(const gw_config& c, double sig_mw, double noise_mw)
+{
+    volatile double euler = M_E;                   // keep pow() a runtime libm call
+    const double s = 10 * log10(sig_mw);
+    const double n = 10 * log10(noise_mw);
+    if (s <= n) return 0.5;
+    const double ratio_db = s - n - 10 * log10(c.bit_rate);
+    const double ratio = pow(10.0, ratio_db / 10);
+    const double x = sqrt(2 * ratio);
+    const double sqrt2pi = sqrt(2 * M_PI);
+    return (1 - pow(euler, -1.4 * x)) * pow(euler, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
+}
+
+} // namespace
+
+int gw_build_tables(const gw_config& cfg, GwHostTables& t, char* msg, size_t msglen)
+{
+    memset(&t, 0, sizeof t);
+    const int D = cfg.num_devices, R = D + 1;
+    t.D = D; t.R = R;
+    t.thermal = 1.38e-23 * (cfg.temperature_c + 273.15) * cfg.bandwidth * 1000;   // physical.py:71, simple_stack.py:77
+    t.data_rate = cfg.code_rate * cfg.bit_rate;                                     // physical.py:197
+    t.coded_factor = 2 - cfg.code_rate;                                             // physical.py:259-263
+    for (int a = 0; a < R; ++a)
+        for (int b = 0; b < R; ++b) {
+            if (a == b) continue;
+            t.att[a][b] = fspl_db(cfg, a, b);
+            t.prx[a][b] = pow(10.0, (cfg.tx_power_dbm - t.att[a][b]) / 10);        // simple_stack.py:111
+        }
+
+    // closure of the resting rx-power values of each listener j under g(., p_ij)
+    for (int j = 0; j < R; ++j) {
+        int n = 1;
+        t.state_val[j][0] = t.thermal;
+        for (int head = 0; head < n; ++head) {
+            const double a = t.state_val[j][head];
+            for (int i = 0; i < R; ++i) {
+                if (i == j) continue;
+                const double p = t.prx[i][j];
+                volatile double up = a + p;                      // simple_stack.py:82 (+p)
+                volatile double b = up + (-p);                   // simple_stack.py:154 (-p)
+                int idx = -1;
+                for (int k = 0; k < n; ++k)
+                    if (memcmp(&t.state_val[j][k], (const void*)&b, sizeof(double)) == 0) { idx = k; break; }
+                if (idx < 0) {
+                    if (n == GW_MAX_NSTATES) {
+                        snprintf(msg, msglen, "rx-power state closure of radio %d exceeds %d states", j, GW_MAX_NSTATES);
+                        return GW_EUNSUPPORTED;
+                    }
+                    idx = n;
+                    t.state_val[j][n++] = b;
+                }
+                const size_t at = ((size_t)j * R + i) * GW_MAX_NSTATES + head;
+                t.trans[at] = (uint8_t)idx;
+            }
+        }
+        t.nstates[j] = n;
+        // BER while j listens to i, indexed by the state AFTER the transition
+        // (noise = fl(a+p) - p = new resting value)            simple_stack.py:161-173
+        for (int i = 0; i < R; ++i) {
+            if (i == j) continue;
+            for (int s = 0; s < n; ++s) {
+                const double noise = t.state_val[j][s];
+                if (!(noise >= 0)) {
+                    snprintf(msg, msglen, "negative noise power for radio %d (the reference asserts here)", j);
+                    return GW_EUNSUPPORTED;
+                }
+                t.ber[((size_t)j * R + i) * GW_MAX_NSTATES + s] = ber_bpsk(cfg, t.prx[i][j], noise);
+            }
+        }
+    }
+    return GW_OK;
+}

@@ -1,0 +1,301 @@
+"""
+Host-side mirror of gymwipe/envs/counter_traffic.py on top of the HIP C-ABI.
+
+``VecCounterTrafficEnv``  N independent CounterTraffic environments resident in HBM on one
+                          GPU, advanced together by one kernel launch per ``step``.
+``CounterTrafficEnv``     the N = 1 drop-in with the reference's exact Python surface:
+                          ``step({"device": int, "duration": int}) -> (int, float, bool, dict)``.
+
+Reference behaviour kept on purpose:
+  * ``reset()`` zeroes the counters and the interpreter only; simulated time, MAC queues
+    and radio state persist (counter_traffic.py:135-144)
+  * a fresh env starts with counters at 1, a reset env at 0 (:48 vs :140)
+  * data payloads carry ``value == 2`` and ``byteSize == counter`` (swapped constructor
+    arguments, :57), so observations are 65534 / 65536 / 65538 and ``done`` never fires
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _native as nat
+from .. import spaces
+from .core import BaseEnv, Interpreter
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class _DeviceInterpreter(Interpreter):
+    """Facade over the interpreter state that lives on the GPU
+    (CounterTrafficEnv.CounterTrafficInterpreter, counter_traffic.py:63-112)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def reset(self):
+        self._env.reset()
+
+    def onPacketReceived(self, senderIndex, receiverIndex, payload):
+        raise NotImplementedError("packets are interpreted inside the HIP step kernel")
+
+    @property
+    def receivedValues(self):
+        rv = self._env.received()
+        return rv[0].tolist() if self._env._scalar_api else rv
+
+    def getObservation(self):
+        return self._env._last[0]
+
+    def getReward(self):
+        return self._env._last[1]
+
+    def getDone(self):
+        return self._env._last[2]
+
+    def getInfo(self):
+        return self._env._info()
+
+
+class VecCounterTrafficEnv(BaseEnv):
+    """N CounterTraffic environments on one MI355X.
+
+    Args:
+        num_envs: N.
+        num_devices: D assignable senders (reference: 2).  For D > 2 the senders sit on a
+            circle of radius 2 m around the RRM with multiplicities 1,3,1,3,....
+        device: torch device string or index ('cuda:0').
+        positions / multiplicity / dest / rrm_position: optional overrides of the layout.
+        per_env_stats: keep per-env event counters (tests; costs HBM traffic).
+        reuse_outputs: return the same output tensors every step (fast path).
+    """
+    COUNTER_INTERVAL = 0.001                              # counter_traffic.py:31
+    COUNTER_BYTE_LENGTH = 2                               # :33
+    COUNTER_BOUND = 2 ** (8 * COUNTER_BYTE_LENGTH)        # :35
+
+    _scalar_api = False
+
+    def __init__(self, num_envs, num_devices=2, device="cuda:0", positions=None,
+                 multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
+                 reuse_outputs=True):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self._L = nat.lib()
+        self.num_envs = int(num_envs)
+        self.num_devices = int(num_devices)
+        self.device = torch.device(device)
+        BaseEnv.__init__(self, self.num_devices)
+        self.observation_space = spaces.Discrete(2 * self.COUNTER_BOUND)   # :120
+
+        cfg = nat.default_config(self.num_envs, self.num_devices)
+        cfg.hip_device = self.device.index or 0
+        D = self.num_devices
+        if positions is not None:
+            assert len(positions) == D
+            for i, (x, y) in enumerate(positions):
+                cfg.pos[i][0], cfg.pos[i][1] = float(x), float(y)
+        if rrm_position is not None:
+            cfg.pos[D][0], cfg.pos[D][1] = float(rrm_position[0]), float(rrm_position[1])
+        if multiplicity is not None:
+            assert len(multiplicity) == D
+            for i, m in enumerate(multiplicity):
+                cfg.mult[i] = int(m)
+        if dest is not None:
+            assert len(dest) == D
+            for i, m in enumerate(dest):
+                cfg.dest[i] = int(m)
+        if per_env_stats:
+            cfg.flags |= nat.CFG_PER_ENV_STATS
+        self.config = cfg
+
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_create(C.byref(cfg), C.byref(self._h)))
+            n = self.num_envs
+            self._obs = torch.empty(n, dtype=torch.int32, device=self.device)
+            self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._done = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._reuse = bool(reuse_outputs)
+        self._last = (None, None, None)
+        self.interpreter = _DeviceInterpreter(self)
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _stream(self):
+        return _torch().cuda.current_stream(self.device).cuda_stream
+
+    def _as_i32(self, x, name):
+        torch = _torch()
+        if isinstance(x, torch.Tensor):
+            t = x
+        else:
+            t = torch.as_tensor(np.asarray(x))
+        if t.dim() == 0:
+            t = t.reshape(1)
+        if t.shape != (self.num_envs,):
+            raise AssertionError("action[%r] must have shape (%d,), got %s"
+                                 % (name, self.num_envs, tuple(t.shape)))
+        return t.to(device=self.device, dtype=torch.int32).contiguous()
+
+    def _outputs(self):
+        if self._reuse:
+            return self._obs, self._rew, self._done
+        torch = _torch()
+        n = self.num_envs
+        return (torch.empty(n, dtype=torch.int32, device=self.device),
+                torch.empty(n, dtype=torch.float32, device=self.device),
+                torch.empty(n, dtype=torch.uint8, device=self.device))
+
+    def _info(self):
+        return {}
+
+    # -- gym surface ----------------------------------------------------------------------------
+    def reset(self, mask=None):
+        """Mirror of CounterTrafficEnv.reset (counter_traffic.py:135-144) for every env, or for
+        the envs selected by ``mask`` (bool/uint8 [N])."""
+        torch = _torch()
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            assert m.shape == (self.num_envs,)
+        obs = self._outputs()[0]
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_reset(self._h, m.data_ptr() if m is not None else None,
+                                       obs.data_ptr(), self._stream()))
+        return obs
+
+    def step(self, action):
+        """One env.step() for all N envs: ``action = {"device": int32[N], "duration": int32[N]}``
+        (torch tensors on the env's GPU are used in place).  Returns
+        ``(obs int32[N], reward float32[N], done uint8[N], info)``; an action outside the action
+        space flags its env (``check()`` raises) and leaves that env untouched."""
+        dev = self._as_i32(action["device"], "device")
+        dur = self._as_i32(action["duration"], "duration")
+        obs, rew, done = self._outputs()
+        with _torch().cuda.device(self.device):
+            nat.check(self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(),
+                                      rew.data_ptr(), done.data_ptr(), self._stream()))
+        self._last = (obs, rew, done)
+        return obs, rew, done, self._info()
+
+    def rollout(self, device, duration, out=None):
+        """K consecutive steps from pre-staged actions ``int32[K][N]``; one launch per step, no
+        Python in between.  Returns ``(obs[K][N], reward[K][N], done[K][N])``."""
+        torch = _torch()
+        dev = torch.as_tensor(device).to(device=self.device, dtype=torch.int32).contiguous()
+        dur = torch.as_tensor(duration).to(device=self.device, dtype=torch.int32).contiguous()
+        K = dev.shape[0]
+        assert dev.shape == (K, self.num_envs) and dur.shape == dev.shape
+        if out is None:
+            out = (torch.empty((K, self.num_envs), dtype=torch.int32, device=self.device),
+                   torch.empty((K, self.num_envs), dtype=torch.float32, device=self.device),
+                   torch.empty((K, self.num_envs), dtype=torch.uint8, device=self.device))
+        obs, rew, done = out
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_rollout(self._h, K, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(),
+                                         rew.data_ptr(), done.data_ptr(), self._stream()))
+        if K:
+            self._last = (obs[-1], rew[-1], done[-1])
+        return obs, rew, done
+
+    def render(self, mode='human', close=False):          # counter_traffic.py:160-162
+        values = self.received()[0].tolist()
+        print("Last Received: {}, difference: {:6d}".format(values, values[1] - values[0]), end='\r')
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.gw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state access ---------------------------------------------------------------------------
+    def received(self):
+        """interpreter.receivedValues of every env: int32[N][D] tensor on the GPU."""
+        torch = _torch()
+        out = torch.empty((self.num_envs, self.num_devices), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_received(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    _FIELDS = {
+        "now": (np.float64, lambda D, R: ()), "wake": (np.float64, lambda D, R: (D,)),
+        "counter": (np.uint32, lambda D, R: (D,)), "qlen": (np.int32, lambda D, R: (D,)),
+        "queue": (np.uint32, lambda D, R: (D, nat.QUEUE_CAP)),
+        "received": (np.int32, lambda D, R: (D,)), "latest_diff": (np.int32, lambda D, R: ()),
+        "last_abs": (np.int32, lambda D, R: ()), "rx_power": (np.float64, lambda D, R: (R,)),
+        "flags": (np.uint32, lambda D, R: ()), "n_tx": (np.uint64, lambda D, R: ()),
+        "n_delivered": (np.uint64, lambda D, R: ()), "n_appended": (np.uint64, lambda D, R: ()),
+        "n_popped": (np.uint64, lambda D, R: ()), "n_dropped": (np.uint64, lambda D, R: ()),
+    }
+
+    def get_state(self, field):
+        """Synchronous host copy of one state field (numpy), in the oracle's logical layout."""
+        dtype, shp = self._FIELDS[field]
+        out = np.empty((self.num_envs,) + shp(self.num_devices, self.num_devices + 1), dtype)
+        nat.check(self._L.gw_get_state(self._h, field.encode(), out.ctypes.data, out.nbytes))
+        return out
+
+    def stats(self):
+        s = nat.Stats()
+        nat.check(self._L.gw_stats_read(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def state_bytes(self):
+        b = C.c_uint64()
+        nat.check(self._L.gw_state_bytes(self._h, C.byref(b)))
+        return int(b.value)
+
+    def link_info(self, frm, to):
+        a, p = C.c_double(), C.c_double()
+        nat.check(self._L.gw_link_info(self._h, frm, to, C.byref(a), C.byref(p)))
+        return a.value, p.value
+
+    def noise_states(self, radio):
+        n = C.c_int32()
+        vals = (C.c_double * nat.MAX_NSTATES)()
+        nat.check(self._L.gw_noise_states(self._h, radio, C.byref(n), vals))
+        return [vals[i] for i in range(n.value)]
+
+    def check(self):
+        """Raise if any env hit a condition outside the modelled horizon or got a bad action."""
+        st = self.stats()
+        fl = st["flags_or"]
+        if fl & nat.FLAG_BADACT:
+            raise AssertionError("%d env-step(s) had an action outside the action space" % st["bad_actions"])
+        if fl & (nat.FLAG_CARRY | nat.FLAG_REFEXC):
+            raise RuntimeError("step horizon not closed in some env (flags 0x%x)" % fl)
+        return st
+
+
+class CounterTrafficEnv(VecCounterTrafficEnv):
+    """Drop-in for gymwipe.envs.CounterTrafficEnv (2 senders + RRM, one env): Python scalars in,
+    Python scalars out, ``AssertionError`` on an action outside the action space
+    (counter_traffic.py:146-158)."""
+    _scalar_api = True
+
+    def __init__(self, device="cuda:0", num_devices=2, **kw):
+        VecCounterTrafficEnv.__init__(self, 1, num_devices=num_devices, device=device,
+                                      reuse_outputs=True, **kw)
+        torch = _torch()
+        self._act = torch.zeros((2, 1), dtype=torch.int32, device=self.device)
+
+    def _info(self):
+        return {"Latest received values": str(self.received()[0].tolist())}   # :109-112
+
+    def reset(self):
+        return int(VecCounterTrafficEnv.reset(self).item())
+
+    def step(self, action):
+        assert self.action_space.contains(action)                              # :147
+        self._act[0, 0] = int(action["device"])
+        self._act[1, 0] = int(action["duration"])
+        obs, rew, done, _ = VecCounterTrafficEnv.step(self, {"device": self._act[0], "duration": self._act[1]})
+        self._last = (int(obs.item()), float(rew.item()), bool(done.item()))
+        return self._last + (self._info(),)

@@ -1,0 +1,149 @@
+/*
+ * gymwipe_amd.h -- C-ABI of the MI355X-native vectorised Gym-WiPE env.step().
+ *
+ * Drop-in boundary for ONE path of the reference (Gryph66/gymwipe): the
+ * discrete-event advance behind the frequency-band-assignment environment
+ * `CounterTrafficEnv` (gymwipe/envs/counter_traffic.py).  N independent
+ * environments live structure-of-arrays in HBM and are advanced by hand-written
+ * HIP kernels for gfx950.  There is NO CPU fallback in this library: every
+ * compute entry point needs a HIP device and fails loudly without one.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative GW_E* code;
+ *     gw_last_error() returns a thread-local message for the last failure
+ *   - `*_dev` pointers are DEVICE pointers owned by the caller (e.g. torch
+ *     tensors), contiguous, length num_envs unless stated; `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream); gw_step/gw_reset are
+ *     asynchronous on that stream and allocate nothing
+ *   - one gw_env per GPU; a handle is not thread-safe; different handles may be
+ *     driven from different host threads
+ *
+ * Reference interface each entry point replaces (file:line in the reference):
+ *   gw_config_default  class constants: envs/core.py:25,27; counter_traffic.py:31-35,124-127;
+ *                      simple_stack.py:27,57,361,364; physical.py:192-197,298; messages.py:154,180
+ *   gw_create          CounterTrafficEnv.__init__            counter_traffic.py:114-133
+ *   gw_reset           CounterTrafficEnv.reset               counter_traffic.py:135-144
+ *   gw_step            CounterTrafficEnv.step                counter_traffic.py:146-158
+ *                        -> SimpleRrmDevice.assignFrequencyBand   networking/devices.py:178-203
+ *                        -> SimMan.runSimulation(eProcessed)      simtools.py:77-88
+ *                        -> Interpreter.getFeedback               envs/core.py:142-153
+ *   gw_received        CounterTrafficInterpreter.receivedValues / getInfo   counter_traffic.py:72,109-112
+ *   gw_get_state       attribute reads the reference's tests perform: SimMan.now, sender.counter,
+ *                      sender._mac._packetQueue, phy._receivedPower
+ *   gw_destroy         (garbage collection)
+ */
+#ifndef GYMWIPE_AMD_H
+#define GYMWIPE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GW_ABI_VERSION   1
+
+#define GW_MAX_DEVICES   32                 /* assignable senders per env */
+#define GW_MAX_RADIOS    (GW_MAX_DEVICES + 1)
+#define GW_QUEUE_CAP     100                /* simple_stack.py:361 deque(maxlen=100) */
+
+/* error codes */
+#define GW_OK             0
+#define GW_EINVAL        -1                 /* bad argument / config */
+#define GW_ENODEVICE     -2                 /* no usable HIP device */
+#define GW_EHIP          -3                 /* HIP runtime error (message has details) */
+#define GW_ENOMEM        -4
+#define GW_EUNSUPPORTED  -5                 /* config outside what the kernels model */
+#define GW_EFIELD        -6                 /* unknown gw_get_state field / size mismatch */
+
+/* per-env sticky flag bits (gw_get_state "flags"; OR over envs in gw_stats) */
+#define GW_FLAG_CARRY    1u   /* a transmission would outlive its step: horizon not closed */
+#define GW_FLAG_REFEXC   2u   /* the reference would raise here (simple_stack.py:166 KeyError) */
+#define GW_FLAG_TIE      4u   /* an exact f64 time tie was resolved by the insertion-order rule */
+#define GW_FLAG_BADACT   8u   /* action outside the action space: env left untouched this step */
+
+typedef struct gw_config {
+    int32_t abi_version;                    /* GW_ABI_VERSION */
+    int32_t hip_device;                     /* device ordinal */
+    int64_t num_envs;                       /* N */
+    int32_t num_devices;                    /* D senders; radio index D is the RRM */
+    int32_t flags;                          /* GW_CFG_* */
+    double  pos[GW_MAX_RADIOS][2];          /* metres; [D] = RRM */
+    int32_t mult[GW_MAX_DEVICES];           /* packets per counter tick (packetMultiplicity) */
+    int32_t dest[GW_MAX_DEVICES];           /* destination sender index */
+    double  slot;                           /* TIME_SLOT_LENGTH 1e-6 s */
+    double  frequency;                      /* 2.4e9 Hz */
+    double  bandwidth;                      /* 22e6 Hz */
+    double  temperature_c;                  /* 20.0 */
+    double  bit_rate;                       /* 133.33333e3 bps */
+    double  code_rate;                      /* 3/4 */
+    double  max_ber;                        /* 0.25 (Varshamov-Gilbert bound for 3/4) */
+    double  tx_power_dbm;                   /* 0.0 */
+    double  counter_interval;               /* COUNTER_INTERVAL 1e-3 s */
+    int32_t counter_bound;                  /* COUNTER_BOUND 65536 */
+    int32_t payload_value;                  /* 2: value field of every data payload (swapped ctor args) */
+    int32_t mac_header_bytes;               /* 13 */
+    int32_t net_header_bytes;               /* 12 */
+    int32_t duration_factor;                /* ASSIGNMENT_DURATION_FACTOR 1000 */
+    int32_t max_duration;                   /* MAX_ASSIGN_DURATION 20 */
+} gw_config;
+
+#define GW_CFG_PER_ENV_STATS  1             /* keep per-env event counters (tests); costs HBM traffic */
+
+typedef struct gw_stats {                   /* totals since gw_create, over all envs */
+    uint64_t steps;                         /* env-steps executed */
+    uint64_t transmissions;                 /* announcements + data packets */
+    uint64_t delivered;                     /* data packets decoded by the RRM */
+    uint64_t appended;                      /* queue appends  (k_app of SURVEY 8d) */
+    uint64_t popped;                        /* queue pops     (k_pop) */
+    uint64_t dropped;                       /* drop-oldest events */
+    uint64_t flags_or;                      /* OR of all per-env flag words */
+    uint64_t bad_actions;                   /* env-steps skipped for an invalid action */
+} gw_stats;
+
+typedef struct gw_env gw_env;
+
+int         gw_abi_version(void);
+const char* gw_last_error(void);
+int         gw_device_count(int* count);
+
+int gw_config_default(gw_config* cfg, int64_t num_envs, int32_t num_devices);
+
+int gw_create(const gw_config* cfg, gw_env** out);
+int gw_destroy(gw_env* env);
+
+/* reset(): counters <- 0, interpreter <- 0, simulated time NOT rewound.
+ * mask_dev: NULL = all envs, else uint8[N] (non-zero = reset).  obs_dev may be NULL. */
+int gw_reset(gw_env* env, const uint8_t* mask_dev, int32_t* obs_dev, void* stream);
+
+/* one env.step() for all N envs.  device_dev in [0,D), duration_dev in [0,max_duration). */
+int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
+            int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+
+/* K consecutive env.step() calls, one kernel launch each, inputs/outputs laid out [K][N]. */
+int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int32_t* duration_dev,
+               int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+
+/* receivedValues of every env: int32[N][D] (row-major), device pointer. */
+int gw_received(gw_env* env, int32_t* out_dev, void* stream);
+
+/* Synchronous state readers for tests/debugging: copies `field` of every env to HOST memory.
+ *   "now" f64[N] | "wake" f64[N][D] | "counter" u32[N][D] | "qlen" i32[N][D]
+ *   "queue" u32[N][D][GW_QUEUE_CAP] (logical order from the head, zero padded)
+ *   "received" i32[N][D] | "latest_diff" i32[N] | "last_abs" i32[N] | "rx_power" f64[N][R]
+ *   "flags" u32[N] | with GW_CFG_PER_ENV_STATS: "n_tx","n_delivered","n_appended","n_popped","n_dropped" u64[N] */
+int gw_get_state(gw_env* env, const char* field, void* dst_host, size_t bytes);
+
+int gw_stats_read(gw_env* env, gw_stats* out);          /* synchronises the device */
+int gw_state_bytes(gw_env* env, uint64_t* bytes);       /* HBM held by this handle */
+
+/* static link tables (host side, for tests): attenuation dB, rx power mW, thermal mW,
+ * and the rx-power state machine used instead of per-env f64 noise state */
+int gw_link_info(gw_env* env, int32_t from, int32_t to, double* attenuation_db, double* rx_power_mw);
+int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values_mw /* [16] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYMWIPE_AMD_H */

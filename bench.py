@@ -40,7 +40,11 @@ def cpu_baseline(D, seconds_target=12.0):
     """The oracle on the host cores, same action distribution, same reset cadence."""
     import numpy as np
     from oracle.ct_oracle import CtOracle
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))           # the GPU box's CPU share for one GPU
     n_env, K = 256 * cores, 64
     rng = np.random.default_rng(1234)
     dev = rng.integers(0, D, (K, n_env), dtype=np.int32)

@@ -19,11 +19,12 @@ MAX_NSTATES = 16
 OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED, EFIELD = 0, -1, -2, -3, -4, -5, -6
 FLAG_CARRY, FLAG_REFEXC, FLAG_TIE, FLAG_BADACT = 1, 2, 4, 8
 CFG_PER_ENV_STATS = 1
+CFG_EXPLICIT_QUEUE = 2
 
 EXPORTS = (
     "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
     "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_get_state",
-    "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states",
+    "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_rle",
 )
 
 
@@ -116,6 +117,7 @@ def lib():
     L.gw_link_info.restype = C.c_int
     L.gw_noise_states.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_double)]
     L.gw_noise_states.restype = C.c_int
+    L.gw_selftest_rle.argtypes, L.gw_selftest_rle.restype = [C.c_uint64, i32, i32, i32], C.c_int
     if L.gw_abi_version() != ABI_VERSION:
         raise ImportError("gymwipe_amd: ABI mismatch (library %d, python %d); rebuild"
                           % (L.gw_abi_version(), ABI_VERSION))

@@ -1,0 +1,81 @@
+// ct_common.hip.h -- device helpers shared by the step kernels (explicit-ring and run-length).
+// Every f64 expression follows the reference's operation order; compile with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gw_internal.h"
+#include "gw_rle.h"
+
+namespace gwk {
+
+typedef GwTally Tally;
+
+struct TxTimes { double t_s, t_h, t_e, stop; };
+
+// simple_stack.py:204 (next slot; a FULL slot when already aligned) +
+// physical.py:244-279 (durations) + simtools.py:112-116 (events fire at now + (t - now))
+__device__ __forceinline__ TxTimes tx_times(double cur, double slot, double hd, double pd)
+{
+    TxTimes x;
+    x.t_s = cur + (slot - fmod(cur, slot));
+    const double dur = hd + pd;
+    x.stop = x.t_s + dur;
+    const double th = x.t_s + hd;
+    x.t_h = (th > x.t_s) ? x.t_s + (th - x.t_s) : x.t_s + 0.0;
+    x.t_e = (x.stop > x.t_s) ? x.t_s + (x.stop - x.t_s) : x.t_s + 0.0;
+    return x;
+}
+
+// simple_stack.py:214-286 with nothing else on the air: header decision at t_h, then the
+// payload error sum counted twice from the same segment start (:180-188,:223-231,:252).
+__device__ __forceinline__ bool receive(double ber, const TxTimes& x, double bit_rate,
+                                        double hdr_bits, double pay_bits, double max_ber,
+                                        uint32_t& flags)
+{
+    double err = 0.0 + ber * (x.t_h - x.t_s) * bit_rate;
+    if (!((rint(err) / hdr_bits) <= max_ber)) return false;
+    const double seg = ber * (x.t_e - x.t_h) * bit_rate;
+    if (!(x.t_e >= x.stop)) flags |= GW_FLAG_REFEXC;      // `not t.completed` -> KeyError in the reference
+    err = (0.0 + seg) + seg;
+    return (rint(err) / pay_bits) <= max_ber;
+}
+
+__device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value))
+{
+    int n = 1;
+    while (v >= 10) { v /= 10; ++n; }
+    return n;
+}
+
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
+    return v;
+}
+
+
+// totals: one atomic per wave and counter
+__device__ __forceinline__ void publish_totals(unsigned long long* totals, const Tally& k, uint32_t k_steps,
+                                               uint32_t k_bad, uint32_t fl_new)
+{
+    const uint32_t t_tx = wave_sum(k.tx), t_dl = wave_sum(k.deliv), t_ap = wave_sum(k.app);
+    const uint32_t t_po = wave_sum(k.pop), t_dr = wave_sum(k.drop), t_bad = wave_sum(k_bad);
+    const uint32_t t_st = wave_sum(k_steps), t_fl = wave_or(fl_new);
+    if ((threadIdx.x & 63) == 0) {
+        if (t_st) atomicAdd(&totals[GW_T_STEPS], (unsigned long long)t_st);
+        if (t_tx) atomicAdd(&totals[GW_T_TX], (unsigned long long)t_tx);
+        if (t_ap) atomicAdd(&totals[GW_T_APP], (unsigned long long)t_ap);
+        if (t_dl) atomicAdd(&totals[GW_T_DELIV], (unsigned long long)t_dl);
+        if (t_po) atomicAdd(&totals[GW_T_POP], (unsigned long long)t_po);
+        if (t_dr) atomicAdd(&totals[GW_T_DROP], (unsigned long long)t_dr);
+        if (t_bad) atomicAdd(&totals[GW_T_BAD], (unsigned long long)t_bad);
+        if (t_fl) atomicOr(&totals[GW_T_FLAGS], (unsigned long long)t_fl);
+    }
+}
+
+} // namespace gwk

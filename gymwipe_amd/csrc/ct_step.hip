@@ -19,56 +19,18 @@
 // rx-power residue state machine come from host tables (gw_tables.cpp).
 // Compile with -ffp-contract=off: every f64 result must be the IEEE result of the
 // reference's individual operations.
-#include <hip/hip_runtime.h>
-#include "gw_internal.h"
+#include "ct_common.hip.h"
+
+using namespace gwk;
 
 namespace {
 
 constexpr int kBlock = 64;             // one wavefront per workgroup (v1: thread per env)
 
-struct TxTimes { double t_s, t_h, t_e, stop; };
-
-// simple_stack.py:204 (next slot; a FULL slot when already aligned) +
-// physical.py:244-279 (durations) + simtools.py:112-116 (events fire at now + (t - now))
-__device__ __forceinline__ TxTimes tx_times(double cur, double slot, double hd, double pd)
-{
-    TxTimes x;
-    x.t_s = cur + (slot - fmod(cur, slot));
-    const double dur = hd + pd;
-    x.stop = x.t_s + dur;
-    const double th = x.t_s + hd;
-    x.t_h = (th > x.t_s) ? x.t_s + (th - x.t_s) : x.t_s + 0.0;
-    x.t_e = (x.stop > x.t_s) ? x.t_s + (x.stop - x.t_s) : x.t_s + 0.0;
-    return x;
-}
-
-// simple_stack.py:214-286 with nothing else on the air: header decision at t_h, then the
-// payload error sum counted twice from the same segment start (:180-188,:223-231,:252).
-__device__ __forceinline__ bool receive(double ber, const TxTimes& x, double bit_rate,
-                                        double hdr_bits, double pay_bits, double max_ber,
-                                        uint32_t& flags)
-{
-    double err = 0.0 + ber * (x.t_h - x.t_s) * bit_rate;
-    if (!((rint(err) / hdr_bits) <= max_ber)) return false;
-    const double seg = ber * (x.t_e - x.t_h) * bit_rate;
-    if (!(x.t_e >= x.stop)) flags |= GW_FLAG_REFEXC;      // `not t.completed` -> KeyError in the reference
-    err = (0.0 + seg) + seg;
-    return (rint(err) / pay_bits) <= max_ber;
-}
-
-__device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value))
-{
-    int n = 1;
-    while (v >= 10) { v /= 10; ++n; }
-    return n;
-}
-
 struct Ring {
     uint32_t* base;
     int head, len;
 };
-
-struct Tally { uint32_t app, pop, drop, tx, deliv; };
 
 // one counter tick: counter_traffic.py:53-61 -> devices.py:84-86 -> simple_stack.py:463-471
 __device__ __forceinline__ void tick_append(Ring& r, uint32_t size, int mult, Tally& k)
@@ -99,17 +61,6 @@ __device__ __forceinline__ void ticks_until(Ring& r, double& wake, uint32_t& ctr
             wake = w + interval;                          // running sum, not k*dt
         } else break;
     }
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_or(uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
-    return v;
 }
 
 template <bool PER_ENV_STATS>
@@ -290,20 +241,7 @@ __global__ __launch_bounds__(kBlock) void ct_step_kernel(GwState st,
         fl_new = fl;
     }
 
-    // ---- totals: one atomic per wave and counter ---------------------------------------------
-    const uint32_t t_tx = wave_sum(k.tx), t_dl = wave_sum(k.deliv), t_ap = wave_sum(k.app);
-    const uint32_t t_po = wave_sum(k.pop), t_dr = wave_sum(k.drop), t_bad = wave_sum(k_bad);
-    const uint32_t t_st = wave_sum(k_steps), t_fl = wave_or(fl_new);
-    if (threadIdx.x == 0) {
-        atomicAdd(&st.totals[GW_T_STEPS], (unsigned long long)t_st);
-        atomicAdd(&st.totals[GW_T_TX], (unsigned long long)t_tx);
-        atomicAdd(&st.totals[GW_T_APP], (unsigned long long)t_ap);
-        if (t_dl) atomicAdd(&st.totals[GW_T_DELIV], (unsigned long long)t_dl);
-        if (t_po) atomicAdd(&st.totals[GW_T_POP], (unsigned long long)t_po);
-        if (t_dr) atomicAdd(&st.totals[GW_T_DROP], (unsigned long long)t_dr);
-        if (t_bad) atomicAdd(&st.totals[GW_T_BAD], (unsigned long long)t_bad);
-        if (t_fl) atomicOr(&st.totals[GW_T_FLAGS], (unsigned long long)t_fl);
-    }
+    publish_totals(st.totals, k, k_steps, k_bad, fl_new);
 }
 
 // fresh env: counters 1 (counter_traffic.py:48), first tick at t=0, all radios at thermal noise
@@ -320,7 +258,7 @@ __global__ void ct_init_kernel(GwState st)
     st.last_abs[e] = 0;
     st.done[e] = 0;
     st.flags[e] = 0u;
-    for (int i = 0; i < D; ++i) st.qhl[(int64_t)i * N + e] = 0;
+    if (st.qhl) for (int i = 0; i < D; ++i) st.qhl[(int64_t)i * N + e] = 0;
     for (int r = 0; r < R; ++r) st.rxs[(int64_t)r * N + e] = 0;
     if (st.pe_stats) for (int s = 0; s < 5; ++s) st.pe_stats[(int64_t)s * N + e] = 0ull;
 }

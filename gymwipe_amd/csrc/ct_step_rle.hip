@@ -1,0 +1,247 @@
+// ct_step_rle.hip -- the default step kernel: MAC queues held as runs of counter ticks.
+//
+// Why: in CounterTraffic every packet a sender enqueues at a counter tick has size
+// 25 + c bytes, `mult` copies per tick, and c advances by one per tick until it
+// saturates at COUNTER_BOUND (counter_traffic.py:53-61).  A queue is therefore a short
+// list of runs (c_first, n_ticks) -- a new run starts only after a reset() -- plus how
+// many packets of the head tick are already gone.  deque(maxlen=100).append
+// (simple_stack.py:361,469) keeps "the last 100 of old ++ new", which is closed-form on
+// runs.  So a tick is a register increment instead of `mult` scattered 4-byte stores,
+// the window loop (simple_stack.py:397-434) never loads from memory after a store, and
+// per (sender, env) one 16-byte word {meta, head run, tail run} is loaded and stored.
+// The encoding is exact: gw_get_state("queue") expands it and the tests compare that
+// with the oracle's explicit deque element by element.
+//
+// Layout per (sender i, env e): rq[(i*N + e)*4 + {0,1,2}] = meta, head run, tail run
+//   nruns == 0: empty.  nruns == 1: the only run is the TAIL word.  nruns >= 2: head and
+//   tail words plus nruns-2 middle runs in rmid[e][i][(mhead + j) & 127].
+//   The head run is kept normalised: its first tick is the queue's head tick.
+#include "ct_common.hip.h"
+#include "gw_rle.h"
+
+using namespace gwk;
+
+namespace {
+
+constexpr int kBlock = 64;
+
+template <int DT, bool PER_ENV_STATS>
+__global__ __launch_bounds__(kBlock) void ct_step_rle_kernel(GwState st,
+                                                            const int32_t* __restrict__ device,
+                                                            const int32_t* __restrict__ duration,
+                                                            int32_t* __restrict__ obs,
+                                                            float* __restrict__ reward,
+                                                            uint8_t* __restrict__ done)
+{
+    const int64_t N = st.N;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const GwDevConst& c = *st.cst;
+    const int D = DT > 0 ? DT : c.D;
+    const int R = D + 1, S = c.S, RRM = D;
+
+    Tally k = {0, 0, 0, 0, 0};
+    uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
+
+    if (e < N) {
+        const int d = device[e];
+        const int du = duration[e];
+        uint32_t rvm = st.rvmask[e];
+        int32_t last_abs = st.last_abs[e];
+        uint8_t dn = st.done[e];
+        const int pv = c.payload_value;
+        uint32_t fl = 0;
+
+        if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
+            // counter_traffic.py:147 asserts; a batched step cannot raise per env: flag + skip
+            fl = GW_FLAG_BADACT;
+            k_bad = 1;
+            const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
+            obs[e] = latest + c.counter_bound;
+            reward[e] = 0.0f;
+            done[e] = dn;
+        } else {
+            k_steps = 1;
+            const double slot = c.slot, dr = c.data_rate, br = c.bit_rate;
+            const double hd = c.hdr_dur, hdr_bits = c.hdr_bits, max_ber = c.max_ber;
+            const double interval = c.counter_interval;
+            const uint32_t bound = (uint32_t)c.counter_bound;
+            const uint32_t base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
+            const int mh = c.mac_hdr;
+
+            // ---- every load of the step is issued here, before anything is stored -------------
+            const double t_a = st.now[e];
+            const double wake0 = st.wake[e];
+            const uint32_t ctr0 = st.counter[e];
+            const uint4* rq4 = reinterpret_cast<const uint4*>(st.rq);
+            const uint4 wd = rq4[(int64_t)d * N + e];
+            uint4 wi[DT > 0 ? DT : 1];
+            if (DT > 0) {
+#pragma unroll
+                for (int i = 0; i < DT; ++i) wi[i] = rq4[(int64_t)i * N + e];
+            }
+            uint8_t s_d = st.rxs[(int64_t)d * N + e];
+            uint8_t s_r = st.rxs[(int64_t)RRM * N + e];
+            const uint8_t s_d_old = s_d, s_r_old = s_r;
+
+            const int slots = du * c.duration_factor;                     // counter_traffic.py:149
+
+            // ---- A.1 / A.2: announcement ------------------------------------------------------
+            const int L = ndigits(slots);
+            const TxTimes an = tx_times(t_a, slot, hd, (double)(L * 8) / dr);
+            k.tx++;
+            s_d = st.trans[((int64_t)d * R + RRM) * S + s_d];
+            const double ber_a = st.ber[((int64_t)d * R + RRM) * S + s_d];
+            const bool granted = receive(ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, max_ber, fl);
+            const double t_r = an.t_e;
+            const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
+
+            // ---- A.3: window at sender d ------------------------------------------------------
+            RQ qd;
+            rq_unpack(qd, wd.x, wd.y, wd.z, st.rmid + (((int64_t)e * D + d) << 7));
+            const uint32_t mult_d = (uint32_t)c.mult[d];
+            double wake = wake0;
+            uint32_t ctr = ctr0;
+            uint32_t n_ticks = 0;
+            int n_data = 0;
+
+            // one counter tick of sender d at time `wake`
+            auto tick_d = [&]() {
+                rq_append(qd, ctr, 1u, mult_d, bound, k);
+                if (ctr < bound) ctr++;
+                wake = wake + interval;                                   // running sum, not k*dt
+                n_ticks++;
+            };
+
+            if (granted) {
+                const double total = (double)slots * slot;               // simple_stack.py:400
+                const double stopw = t_r + total;                        // :401 (== timeout time :406)
+                double cur = t_r;
+                // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
+                while (wake < cur) tick_d();
+                for (;;) {
+                    if (qd.len == 0) {                                    // :409-416
+                        if (wake < stopw) { cur = wake; tick_d(); }
+                        else break;
+                    }
+                    const uint32_t s = base_bytes + rq_head_value(qd);
+                    const double need = (double)(s * 8u) / dr;           // messages.py:67-75
+                    if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
+                    rq_consume(qd, 1u, mult_d, bound);                    // :425
+                    k.pop++;
+                    const int pay = (int)s - mh;
+                    const TxTimes x = tx_times(cur, slot, hd, (double)(pay * 8) / dr);
+                    k.tx++;
+                    n_data++;
+                    s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
+                    const double ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
+                    const bool ok = receive(ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, max_ber, fl);
+                    if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
+                        k.deliv++;
+                        rvm |= (1u << d);
+                        if (pv == c.counter_bound) dn = 1;
+                    }
+                    if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
+                    // ticks are older events than the MAC's resume at t_e: they go first
+                    while (wake <= x.t_e) { if (wake == x.t_e) fl |= GW_FLAG_TIE; tick_d(); }
+                    cur = x.t_e;
+                    if (!(cur < stopw)) break;                            // window timeout already processed
+                }
+            }
+
+            // ---- A.5: remaining ticks up to the end of the step -------------------------------
+            while (wake <= t_end) { if (wake == t_end) fl |= GW_FLAG_TIE; tick_d(); }
+            { uint4 o; o.w = 0u; rq_pack(qd, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)d * N + e] = o; }
+
+            // every other sender saw the same n_ticks ticks, values ctr0, ctr0+1, ...
+            if (DT > 0) {
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    if (i == d) continue;
+                    RQ qi;
+                    rq_unpack(qi, wi[i].x, wi[i].y, wi[i].z, st.rmid + (((int64_t)e * D + i) << 7));
+                    rq_bulk(qi, ctr0, n_ticks, (uint32_t)c.mult[i], bound, k);
+                    { uint4 o; o.w = 0u; rq_pack(qi, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)i * N + e] = o; }
+                }
+            } else {
+                for (int i = 0; i < D; ++i) {
+                    if (i == d) continue;
+                    RQ qi;
+                    const uint4 wq = rq4[(int64_t)i * N + e];
+                    rq_unpack(qi, wq.x, wq.y, wq.z, st.rmid + (((int64_t)e * D + i) << 7));
+                    rq_bulk(qi, ctr0, n_ticks, (uint32_t)c.mult[i], bound, k);
+                    { uint4 o; o.w = 0u; rq_pack(qi, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)i * N + e] = o; }
+                }
+            }
+
+            // ---- rx-power state of every radio (simple_stack.py:130-157) --------------------------
+            if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
+            if (s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
+            for (int j = 0; j < D; ++j) {
+                if (j == d) continue;
+                uint8_t s = st.rxs[(int64_t)j * N + e];
+                const uint8_t s0 = s;
+                s = st.trans[((int64_t)j * R + RRM) * S + s];
+                for (int n = 0; n < n_data; ++n) {
+                    const uint8_t s2 = st.trans[((int64_t)j * R + d) * S + s];
+                    if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
+                    s = s2;
+                }
+                if (s != s0) st.rxs[(int64_t)j * N + e] = s;
+            }
+
+            // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------
+            const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
+            const int32_t abs_d = latest < 0 ? -latest : latest;
+            int32_t r = last_abs - abs_d;
+            last_abs = abs_d;
+            r = r > 10 ? 10 : (r < -10 ? -10 : r);
+            obs[e] = latest + c.counter_bound;
+            reward[e] = (float)r;
+            done[e] = dn;
+
+            st.now[e] = t_end;
+            st.wake[e] = wake;
+            st.counter[e] = ctr;
+            st.rvmask[e] = rvm;
+            st.last_abs[e] = last_abs;
+            st.done[e] = dn;
+            if (PER_ENV_STATS) {
+                st.pe_stats[0 * N + e] += k.tx;
+                st.pe_stats[1 * N + e] += k.deliv;
+                st.pe_stats[2 * N + e] += k.app;
+                st.pe_stats[3 * N + e] += k.pop;
+                st.pe_stats[4 * N + e] += k.drop;
+            }
+        }
+        if (fl) st.flags[e] |= fl;                                         // rare: sticky flags
+        fl_new = fl;
+    }
+    publish_totals(st.totals, k, k_steps, k_bad, fl_new);
+}
+
+template <int DT>
+int launch(const GwState& st, const int32_t* device, const int32_t* duration,
+           int32_t* obs, float* reward, uint8_t* done, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + kBlock - 1) / kBlock);
+    if (st.pe_stats)
+        hipLaunchKernelGGL((ct_step_rle_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                           st, device, duration, obs, reward, done);
+    else
+        hipLaunchKernelGGL((ct_step_rle_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                           st, device, duration, obs, reward, done);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
+} // namespace
+
+int gw_launch_step_rle(const GwState& st, const int32_t* device, const int32_t* duration,
+                       int32_t* obs, float* reward, uint8_t* done, void* stream)
+{
+    switch (st.D) {
+    case 2:  return launch<2>(st, device, duration, obs, reward, done, stream);
+    case 4:  return launch<4>(st, device, duration, obs, reward, done, stream);
+    case 8:  return launch<8>(st, device, duration, obs, reward, done, stream);
+    default: return launch<0>(st, device, duration, obs, reward, done, stream);
+    }
+}

@@ -3,6 +3,7 @@
 // There is deliberately no CPU fallback: without a HIP device every compute
 // entry point fails with GW_ENODEVICE.
 #include "gw_internal.h"
+#include "gw_rle.h"
 
 #include <hip/hip_runtime.h>
 
@@ -13,6 +14,7 @@
 #include <string.h>
 #include <new>
 #include <vector>
+#include <deque>
 
 namespace {
 
@@ -67,6 +69,9 @@ int select_device(const gw_env* env)
     return GW_OK;
 }
 
+int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
+                int32_t* obs, float* reward, uint8_t* done, void* stream);
+
 int validate(const gw_config& c)
 {
     if (c.abi_version != GW_ABI_VERSION) return fail(GW_EINVAL, "abi_version %d != %d", c.abi_version, GW_ABI_VERSION);
@@ -81,9 +86,59 @@ int validate(const gw_config& c)
         return fail(GW_EINVAL, "slot, bit_rate, code_rate and counter_interval must be positive");
     if (c.mac_header_bytes < 1 || c.net_header_bytes < 0 || c.counter_bound < 1 || c.duration_factor < 1 || c.max_duration < 1)
         return fail(GW_EINVAL, "header sizes / bounds out of range");
+    if (!(c.flags & GW_CFG_EXPLICIT_QUEUE)) {
+        for (int i = 0; i < c.num_devices; ++i)
+            if (c.mult[i] > GW_MAX_MULT)
+                return fail(GW_EUNSUPPORTED, "mult[%d] > %d needs GW_CFG_EXPLICIT_QUEUE", i, GW_MAX_MULT);
+        if (c.counter_bound > 0x1ffff - 1)
+            return fail(GW_EUNSUPPORTED, "counter_bound > 131070 needs GW_CFG_EXPLICIT_QUEUE");
+    }
     if ((int64_t)c.max_duration * c.duration_factor > 100000000)
         return fail(GW_EINVAL, "max_duration*duration_factor too large");
     return GW_OK;
+}
+
+int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
+                int32_t* obs, float* reward, uint8_t* done, void* stream)
+{
+    return env->st.rq ? gw_launch_step_rle(env->st, device, duration, obs, reward, done, stream)
+                      : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
+}
+
+// Expand the run-length queue {meta, head run, tail run} (+ middle runs) of one (env, sender)
+// into packet byte sizes, head first.  Returns the number of packets or -1 if inconsistent.
+int expand_rle_raw(uint32_t bound, uint32_t base, uint32_t mult, const uint32_t* q4, const uint32_t* mid,
+                   uint32_t* out /* [GW_QUEUE_CAP] */)
+{
+    const uint32_t meta = q4[0];
+    const uint32_t nruns = GW_META_NRUNS(meta), used = GW_META_USED(meta), len = GW_META_LEN(meta);
+    const uint32_t mhead = GW_META_MHEAD(meta);
+    uint32_t pos = 0;
+    bool first_tick = true;
+    for (uint32_t r = 0; r < nruns; ++r) {
+        uint32_t w;
+        if (r == nruns - 1) w = q4[2];                     // the tail word (also the head when nruns == 1)
+        else if (r == 0) w = q4[1];
+        else w = mid[(mhead + r - 1) & GW_RING_MASK];
+        const uint32_t c0 = GW_RUN_C(w), n = GW_RUN_N(w);
+        for (uint32_t t = 0; t < n; ++t) {
+            const uint32_t v = (c0 + t < bound) ? c0 + t : bound;
+            const uint32_t copies = first_tick ? mult - used : mult;
+            first_tick = false;
+            for (uint32_t m = 0; m < copies; ++m) {
+                if (pos >= GW_QUEUE_CAP) return -1;
+                out[pos++] = base + v;
+            }
+        }
+    }
+    return pos == len ? (int)pos : -1;
+}
+
+int expand_rle(const gw_env* env, int sender, const uint32_t* q4, const uint32_t* mid, uint32_t* out)
+{
+    return expand_rle_raw((uint32_t)env->cfg.counter_bound,
+                          (uint32_t)(env->cfg.mac_header_bytes + env->cfg.net_header_bytes),
+                          (uint32_t)env->cfg.mult[sender], q4, mid, out);
 }
 
 } // namespace
@@ -192,7 +247,11 @@ int gw_create(const gw_config* cfg, gw_env** out)
     const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
 #define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
     TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
-    TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
+    if (cfg->flags & GW_CFG_EXPLICIT_QUEUE) {
+        TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
+    } else {
+        TRY_ALLOC(st.rq, N * D * 4);  TRY_ALLOC(st.rmid, N * D * GW_RING_PHYS);
+    }
     TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
     TRY_ALLOC(st.rxs, N * R);  TRY_ALLOC(st.flags, N);
     if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
@@ -206,7 +265,11 @@ int gw_create(const gw_config* cfg, gw_env** out)
     HIP_TRY_D(hipMemcpy(d_trans, env->tab.trans, tcount * sizeof(uint8_t), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_ber, env->tab.ber, tcount * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemset(st.totals, 0, GW_T_COUNT * sizeof(unsigned long long)));
-    HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
+    if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
+    if (st.rq) {
+        HIP_TRY_D(hipMemset(st.rq, 0, (size_t)N * D * 4 * sizeof(uint32_t)));
+        HIP_TRY_D(hipMemset(st.rmid, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
+    }
     rc = gw_launch_init(st, nullptr);
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
     HIP_TRY_D(hipDeviceSynchronize());
@@ -241,7 +304,7 @@ int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
         return fail(GW_EINVAL, "gw_step: NULL device pointer");
     int rc = select_device(env);
     if (rc) return rc;
-    if (gw_launch_step(env->st, device_dev, duration_dev, obs_dev, reward_dev, done_dev, stream))
+    if (launch_step(env, device_dev, duration_dev, obs_dev, reward_dev, done_dev, stream))
         return fail(GW_EHIP, "step kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return GW_OK;
 }
@@ -258,7 +321,7 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
     const int64_t N = env->st.N;
     for (int32_t s = 0; s < steps; ++s) {
         const int64_t o = (int64_t)s * N;
-        if (gw_launch_step(env->st, device_dev + o, duration_dev + o, obs_dev + o, reward_dev + o, done_dev + o, stream))
+        if (launch_step(env, device_dev + o, duration_dev + o, obs_dev + o, reward_dev + o, done_dev + o, stream))
             return fail(GW_EHIP, "step kernel launch failed at step %d", s);
     }
     return GW_OK;
@@ -313,6 +376,69 @@ int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values)
     return GW_OK;
 }
 
+// Host-only fuzz of the run-length queue (gw_rle.h, the same code the kernel runs) against an
+// explicit deque(maxlen=GW_QUEUE_CAP): random ticks (single and bulk), resets and pops.
+// Returns the number of mismatching operations (0 = identical), negative on bad arguments.
+int gw_selftest_rle(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound)
+{
+    if (operations < 0 || mult < 1 || mult > GW_MAX_MULT || counter_bound < 1 || counter_bound > 0x1fffe)
+        return fail(GW_EINVAL, "gw_selftest_rle: bad arguments");
+    uint64_t x = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&x](uint32_t n) {                      // xorshift64*, test-only
+        x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+        return (uint32_t)(((x * 2685821657736338717ull) >> 33) % n);
+    };
+    const uint32_t bound = (uint32_t)counter_bound, base = 25u, m = (uint32_t)mult;
+    std::vector<uint32_t> mid(GW_RING_PHYS, 0u);
+    RQ q;
+    rq_unpack(q, 0u, 0u, 0u, mid.data());
+    std::deque<uint32_t> ref;
+    GwTally tally = {0, 0, 0, 0, 0};
+    uint32_t ctr = 1, bad = 0;
+    uint64_t ref_drops = 0;
+    for (int32_t op = 0; op < operations; ++op) {
+        const uint32_t what = rnd(16);
+        if (what < 9) {                                 // ticks
+            const uint32_t kk = 1 + rnd(what < 5 ? 3 : 22);
+            const bool bulk = rnd(2) != 0;
+            uint32_t c0 = ctr;
+            for (uint32_t t = 0; t < kk; ++t) {
+                for (uint32_t j = 0; j < m; ++j) {
+                    if (ref.size() == GW_QUEUE_CAP) { ref.pop_front(); ++ref_drops; }
+                    ref.push_back(base + ctr);
+                }
+                if (!bulk) rq_append(q, ctr, 1u, m, bound, tally);
+                if (ctr < bound) ++ctr;
+            }
+            if (bulk) rq_bulk(q, c0, kk, m, bound, tally);
+        } else if (what < 11) {                         // reset(): counter_traffic.py:139-140
+            ctr = 0;
+        } else if (what == 11) {                        // jump close to saturation
+            if (bound > 8 && ctr + 8 < bound && rnd(4) == 0) ctr = bound - 1 - rnd(6);
+        } else {                                        // pops
+            uint32_t n = 1 + rnd(what == 15 ? 40 : 4);
+            while (n-- && !ref.empty()) {
+                const uint32_t hv = base + rq_head_value(q);
+                if (hv != ref.front()) ++bad;
+                ref.pop_front();
+                rq_consume(q, 1u, m, bound);
+            }
+        }
+        uint32_t w[3], out[GW_QUEUE_CAP];
+        rq_pack(q, w[0], w[1], w[2]);
+        RQ back;                                        // the packed words must round-trip
+        rq_unpack(back, w[0], w[1], w[2], mid.data());
+        if (back.mhead != q.mhead || back.nruns != q.nruns || back.used != q.used || back.len != q.len ||
+            back.tc != q.tc || back.tn != q.tn || (q.nruns >= 2 && (back.hc != q.hc || back.hn != q.hn))) { ++bad; continue; }
+        const int n = expand_rle_raw(bound, base, m, w, mid.data(), out);
+        bool same = n == (int)ref.size();
+        for (int i = 0; same && i < n; ++i) same = out[i] == ref[(size_t)i];
+        if (!same) ++bad;
+    }
+    if (tally.drop != ref_drops) ++bad;
+    return (int)bad;
+}
+
 int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
 {
     if (!env || !field || !dst) return fail(GW_EINVAL, "env/field/dst is NULL");
@@ -358,6 +484,28 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
             int32_t* o = (int32_t*)dst;
             for (int64_t e = 0; e < N; ++e) o[e] = pv * ((int)(m[e] & 1u) - (int)((m[e] >> 1) & 1u));
         }
+        return GW_OK;
+    }
+    if ((!strcmp(field, "qlen") || !strcmp(field, "queue")) && st.rq) {
+        std::vector<uint32_t> q4((size_t)N * D * 4);
+        HIP_TRY(hipMemcpy(q4.data(), st.rq, q4.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (field[1] == 'l') {
+            NEED(N * D, int32_t);
+            int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e)
+                for (int i = 0; i < D; ++i) o[e * D + i] = (int32_t)GW_META_LEN(q4[((size_t)i * N + e) * 4]);
+            return GW_OK;
+        }
+        NEED(N * D * GW_QUEUE_CAP, uint32_t);
+        std::vector<uint32_t> mid((size_t)N * D * GW_RING_PHYS);
+        HIP_TRY(hipMemcpy(mid.data(), st.rmid, mid.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t* o = (uint32_t*)dst;
+        memset(o, 0, bytes);
+        for (int64_t e = 0; e < N; ++e)
+            for (int i = 0; i < D; ++i)
+                if (expand_rle(env, i, &q4[((size_t)i * N + e) * 4], &mid[((size_t)e * D + i) * GW_RING_PHYS],
+                               o + ((size_t)e * D + i) * GW_QUEUE_CAP) < 0)
+                    return fail(GW_EHIP, "inconsistent run-length queue at env %lld sender %d", (long long)e, i);
         return GW_OK;
     }
     if (!strcmp(field, "qlen") || !strcmp(field, "queue")) {

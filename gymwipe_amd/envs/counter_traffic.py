@@ -68,6 +68,8 @@ class VecCounterTrafficEnv(BaseEnv):
         device: torch device string or index ('cuda:0').
         positions / multiplicity / dest / rrm_position: optional overrides of the layout.
         per_env_stats: keep per-env event counters (tests; costs HBM traffic).
+        explicit_queue: hold the MAC queues as explicit rings of packet sizes (generic, slower)
+            instead of the default exact run-length encoding of counter traffic.
         reuse_outputs: return the same output tensors every step (fast path).
     """
     COUNTER_INTERVAL = 0.001                              # counter_traffic.py:31
@@ -78,7 +80,7 @@ class VecCounterTrafficEnv(BaseEnv):
 
     def __init__(self, num_envs, num_devices=2, device="cuda:0", positions=None,
                  multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
-                 reuse_outputs=True):
+                 reuse_outputs=True, explicit_queue=False, counter_bound=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -109,6 +111,12 @@ class VecCounterTrafficEnv(BaseEnv):
                 cfg.dest[i] = int(m)
         if per_env_stats:
             cfg.flags |= nat.CFG_PER_ENV_STATS
+        if explicit_queue:
+            cfg.flags |= nat.CFG_EXPLICIT_QUEUE
+        if counter_bound is not None:          # tests: reach counter saturation quickly
+            cfg.counter_bound = int(counter_bound)
+            self.COUNTER_BOUND = int(counter_bound)
+            self.observation_space = spaces.Discrete(2 * self.COUNTER_BOUND)
         self.config = cfg
 
         self._h = C.c_void_p()

@@ -90,6 +90,8 @@ typedef struct gw_config {
 } gw_config;
 
 #define GW_CFG_PER_ENV_STATS  1             /* keep per-env event counters (tests); costs HBM traffic */
+#define GW_CFG_EXPLICIT_QUEUE 2             /* MAC queues as explicit rings of packet sizes (generic, slower);
+                                               default: exact run-length encoding of counter traffic */
 
 typedef struct gw_stats {                   /* totals since gw_create, over all envs */
     uint64_t steps;                         /* env-steps executed */
@@ -142,6 +144,10 @@ int gw_state_bytes(gw_env* env, uint64_t* bytes);       /* HBM held by this hand
  * and the rx-power state machine used instead of per-env f64 noise state */
 int gw_link_info(gw_env* env, int32_t from, int32_t to, double* attenuation_db, double* rx_power_mw);
 int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values_mw /* [16] */);
+
+/* Host-only self-test hook (no GPU needed): fuzzes the run-length MAC-queue encoding the kernels use
+ * against an explicit deque(maxlen=100).  Returns the number of mismatches (0 = identical). */
+int gw_selftest_rle(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);
 
 #ifdef __cplusplus
 }

@@ -13,11 +13,18 @@ from util import action_stream, assert_state_equal, STATE_FIELDS, STAT_FIELDS
 pytestmark = pytest.mark.gpu
 
 
-def _mk(num_envs, D, **kw):
+QUEUE_MODES = [pytest.param(False, id="rle"), pytest.param(True, id="explicit")]
+
+
+def _mk(num_envs, D, explicit=False, counter_bound=None, **kw):
     from gymwipe_amd import VecCounterTrafficEnv
-    from oracle.ct_oracle import CtOracle
-    env = VecCounterTrafficEnv(num_envs, num_devices=D, per_env_stats=True, **kw)
-    orc = CtOracle(num_envs, D, nthreads=8)
+    from oracle.ct_oracle import CtOracle, default_config
+    env = VecCounterTrafficEnv(num_envs, num_devices=D, per_env_stats=True, explicit_queue=explicit,
+                               counter_bound=counter_bound, **kw)
+    cfg = default_config(D)
+    if counter_bound is not None:
+        cfg.counter_bound = counter_bound
+    orc = CtOracle(num_envs, D, config=cfg, nthreads=8)
     return env, orc
 
 
@@ -40,18 +47,45 @@ def _run(env, orc, dev, dur, reset_every=None, check_every=16, reset_first=True)
     env.check()
 
 
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
 @pytest.mark.parametrize("D,N,K", [(2, 4096, 96), (4, 4096, 96), (16, 1024, 64)])
-def test_parity_with_resets(D, N, K):
-    env, orc = _mk(N, D)
+def test_parity_with_resets(D, N, K, explicit):
+    env, orc = _mk(N, D, explicit)
     dev, dur = action_stream(100 + D, K, N, D)
     _run(env, orc, dev, dur, reset_every=32)
 
 
-def test_parity_fresh_env_no_reset():
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+def test_parity_fresh_env_no_reset(explicit):
     """The reference's own test never calls reset(): counters start at 1."""
-    env, orc = _mk(2048, 2)
+    env, orc = _mk(2048, 2, explicit)
     dev, dur = action_stream(7, 48, 2048, 2)
     _run(env, orc, dev, dur, reset_first=False)
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+def test_parity_frequent_resets_many_runs(explicit):
+    """reset() every 3 steps: many short runs per queue (middle-run ring, head-run hand-over)."""
+    env, orc = _mk(1024, 4, explicit)
+    dev, dur = action_stream(11, 120, 1024, 4)
+    _run(env, orc, dev, dur, reset_every=3, check_every=8)
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+def test_parity_counter_saturation(explicit):
+    """COUNTER_BOUND lowered to 40 so counters saturate within the rollout (counter_traffic.py:59-60)."""
+    env, orc = _mk(1024, 4, explicit, counter_bound=40)
+    dev, dur = action_stream(12, 64, 1024, 4)
+    _run(env, orc, dev, dur, reset_every=24, check_every=8)
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+def test_parity_long_run_queue_overflow(explicit):
+    """No reset for 160 steps: queues fill to 100 and drop the oldest (simple_stack.py:361)."""
+    env, orc = _mk(512, 2, explicit)
+    dev, dur = action_stream(13, 160, 512, 2)
+    _run(env, orc, dev, dur, check_every=32)
+    assert int(orc.get("n_dropped").min()) > 0
 
 
 def test_reference_known_answer_through_c_abi():

@@ -255,7 +255,8 @@ int gw_create(const gw_config* cfg, gw_env** out)
     TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
     TRY_ALLOC(st.rxs, N * R);  TRY_ALLOC(st.flags, N);
     if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
-    TRY_ALLOC(st.totals, GW_T_COUNT);
+    st.n_slots = (N + 63) / 64;
+    TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
     TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount);  TRY_ALLOC(d_ber, tcount);
 #undef TRY_ALLOC
     st.cst = d_cst; st.trans = d_trans; st.ber = d_ber;
@@ -264,7 +265,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     HIP_TRY_D(hipMemcpy(d_cst, &k, sizeof k, hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_trans, env->tab.trans, tcount * sizeof(uint8_t), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_ber, env->tab.ber, tcount * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY_D(hipMemset(st.totals, 0, GW_T_COUNT * sizeof(unsigned long long)));
+    HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
     if (st.rq) {
         HIP_TRY_D(hipMemset(st.rq, 0, (size_t)N * D * 4 * sizeof(uint32_t)));
@@ -341,9 +342,15 @@ int gw_stats_read(gw_env* env, gw_stats* out)
     if (!env || !out) return fail(GW_EINVAL, "env/out is NULL");
     int rc = select_device(env);
     if (rc) return rc;
-    unsigned long long t[GW_T_COUNT];
+    unsigned long long t[GW_T_COUNT] = {0};
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(t, env->st.totals, sizeof t, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> slots((size_t)env->st.n_slots * GW_T_COUNT);
+    HIP_TRY(hipMemcpy(slots.data(), env->st.totals, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int64_t w = 0; w < env->st.n_slots; ++w)
+        for (int j = 0; j < GW_T_COUNT; ++j) {
+            if (j == GW_T_FLAGS) t[j] |= slots[(size_t)w * GW_T_COUNT + j];
+            else t[j] += slots[(size_t)w * GW_T_COUNT + j];
+        }
     out->steps = t[GW_T_STEPS]; out->transmissions = t[GW_T_TX]; out->delivered = t[GW_T_DELIV];
     out->appended = t[GW_T_APP]; out->popped = t[GW_T_POP]; out->dropped = t[GW_T_DROP];
     out->flags_or = t[GW_T_FLAGS]; out->bad_actions = t[GW_T_BAD];

@@ -40,7 +40,9 @@ struct GwState {
     uint8_t*  rxs;        // [R][N]     rx-power state index per radio (stands for phy._receivedPower)
     uint32_t* flags;      // [N]        sticky GW_FLAG_* bits
     uint64_t* pe_stats;   // [5][N] or nullptr: n_tx, n_delivered, n_appended, n_popped, n_dropped
-    unsigned long long* totals;  // [8] steps, tx, delivered, appended, popped, dropped, flags_or, bad_actions
+    unsigned long long* totals;  // [n_slots][GW_T_COUNT], one 64-B slot per wave of the step launch:
+                                 // steps, tx, delivered, appended, popped, dropped, flags_or, bad_actions
+    int64_t   n_slots;
     const GwDevConst* cst;
     const uint8_t*    trans;     // [R to][R from][S]  state after hearing `from`
     const double*     ber;       // [R to][R from][S]  BER at `to` while hearing `from`, indexed by the NEW state

@@ -32,7 +32,7 @@ for f in find("trace", "*kernel_trace.csv"):
         d = sorted(x[0] for x in v)
         print("%s: n=%d avg=%.0f median=%d min=%d max=%d vgpr=%s sgpr=%s wg=%s grid=%s"
               % (k[:80], len(d), sum(d) / len(d), d[len(d) // 2], d[0], d[-1], v[0][1], v[0][2], v[0][3], v[0][4]))
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in find(sub, "*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:

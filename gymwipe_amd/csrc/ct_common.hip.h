@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "gw_internal.h"
 #include "gw_rle.h"
+#include "gw_fastmath.h"
 
 namespace gwk {
 
@@ -11,12 +12,40 @@ typedef GwTally Tally;
 
 struct TxTimes { double t_s, t_h, t_e, stop; };
 
+// The three f64 operations of the step that are expensive on the device, each with an exact fast
+// form that gw_create validated for this configuration (gw_fastmath.h) and the plain form otherwise.
+struct StepMath {
+    double slot, inv_slot, fmod_limit, dr, rcp_dr, max_ber;
+    int fast_fmod, fast_div, fast_decide;
+
+    __device__ __forceinline__ explicit StepMath(const GwDevConst& c)
+        : slot(c.slot), inv_slot(c.inv_slot), fmod_limit(c.fmod_limit), dr(c.data_rate),
+          rcp_dr(c.rcp_data_rate), max_ber(c.max_ber), fast_fmod(c.fast_fmod), fast_div(c.fast_div),
+          fast_decide(c.fast_decide) {}
+
+    // t % slot                                                       simtools.py:53
+    __device__ __forceinline__ double slot_rem(double t) const
+    {
+        return (fast_fmod && t < fmod_limit) ? gw_fast_fmod(t, slot, inv_slot) : fmod(t, slot);
+    }
+    // bits / dataRate                                                 physical.py:244-247, messages.py:67-75
+    __device__ __forceinline__ double over_rate(double bits) const
+    {
+        return fast_div ? gw_fast_div(bits, dr, rcp_dr) : bits / dr;
+    }
+    // round(errSum)/totalBits <= maxCorrectableBer (banker's rounding) simple_stack.py:269-286
+    __device__ __forceinline__ bool decodes(double err, double bits) const
+    {
+        return fast_decide ? (4.0 * rint(err) <= bits) : ((rint(err) / bits) <= max_ber);
+    }
+};
+
 // simple_stack.py:204 (next slot; a FULL slot when already aligned) +
 // physical.py:244-279 (durations) + simtools.py:112-116 (events fire at now + (t - now))
-__device__ __forceinline__ TxTimes tx_times(double cur, double slot, double hd, double pd)
+__device__ __forceinline__ TxTimes tx_times(const StepMath& m, double cur, double hd, double pd)
 {
     TxTimes x;
-    x.t_s = cur + (slot - fmod(cur, slot));
+    x.t_s = cur + (m.slot - m.slot_rem(cur));
     const double dur = hd + pd;
     x.stop = x.t_s + dur;
     const double th = x.t_s + hd;
@@ -27,16 +56,15 @@ __device__ __forceinline__ TxTimes tx_times(double cur, double slot, double hd, 
 
 // simple_stack.py:214-286 with nothing else on the air: header decision at t_h, then the
 // payload error sum counted twice from the same segment start (:180-188,:223-231,:252).
-__device__ __forceinline__ bool receive(double ber, const TxTimes& x, double bit_rate,
-                                        double hdr_bits, double pay_bits, double max_ber,
-                                        uint32_t& flags)
+__device__ __forceinline__ bool receive(const StepMath& m, double ber, const TxTimes& x, double bit_rate,
+                                        double hdr_bits, double pay_bits, uint32_t& flags)
 {
     double err = 0.0 + ber * (x.t_h - x.t_s) * bit_rate;
-    if (!((rint(err) / hdr_bits) <= max_ber)) return false;
+    if (!m.decodes(err, hdr_bits)) return false;
     const double seg = ber * (x.t_e - x.t_h) * bit_rate;
     if (!(x.t_e >= x.stop)) flags |= GW_FLAG_REFEXC;      // `not t.completed` -> KeyError in the reference
     err = (0.0 + seg) + seg;
-    return (rint(err) / pay_bits) <= max_ber;
+    return m.decodes(err, pay_bits);
 }
 
 __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value))
@@ -47,14 +75,15 @@ __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 l
 }
 
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+// reductions over the ACTIVE width of a wave (blocks narrower than 64 leave the upper lanes unborn)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v, int width = 64)
 {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
-__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v, int width = 64)
 {
-    for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
+    for (int off = width >> 1; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
     return v;
 }
 
@@ -65,11 +94,13 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 __device__ __forceinline__ void publish_totals(unsigned long long* totals, const Tally& k, uint32_t k_steps,
                                                uint32_t k_bad, uint32_t fl_new)
 {
-    const uint32_t t_tx = wave_sum(k.tx), t_dl = wave_sum(k.deliv), t_ap = wave_sum(k.app);
-    const uint32_t t_po = wave_sum(k.pop), t_dr = wave_sum(k.drop), t_bad = wave_sum(k_bad);
-    const uint32_t t_st = wave_sum(k_steps), t_fl = wave_or(fl_new);
+    const int w = blockDim.x < 64 ? (int)blockDim.x : 64;
+    const uint32_t t_tx = wave_sum(k.tx, w), t_dl = wave_sum(k.deliv, w), t_ap = wave_sum(k.app, w);
+    const uint32_t t_po = wave_sum(k.pop, w), t_dr = wave_sum(k.drop, w), t_bad = wave_sum(k_bad, w);
+    const uint32_t t_st = wave_sum(k_steps, w), t_fl = wave_or(fl_new, w);
     if ((threadIdx.x & 63) == 0) {
-        const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const size_t waves_per_block = (blockDim.x + 63) >> 6;
+        const size_t wave = (size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
         unsigned long long* t = totals + wave * GW_T_COUNT;
         t[GW_T_STEPS] += t_st;
         t[GW_T_TX] += t_tx;

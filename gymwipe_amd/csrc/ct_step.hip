@@ -25,7 +25,6 @@ using namespace gwk;
 
 namespace {
 
-constexpr int kBlock = 64;             // one wavefront per workgroup (v1: thread per env)
 
 struct Ring {
     uint32_t* base;
@@ -64,7 +63,7 @@ __device__ __forceinline__ void ticks_until(Ring& r, double& wake, uint32_t& ctr
 }
 
 template <bool PER_ENV_STATS>
-__global__ __launch_bounds__(kBlock) void ct_step_kernel(GwState st,
+__global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                                                         const int32_t* __restrict__ device,
                                                         const int32_t* __restrict__ duration,
                                                         int32_t* __restrict__ obs,
@@ -72,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void ct_step_kernel(GwState st,
                                                         uint8_t* __restrict__ done)
 {
     const int64_t N = st.N;
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const GwDevConst& c = *st.cst;
     const int D = c.D, R = c.R, S = c.S, RRM = c.D;
 
@@ -99,8 +98,9 @@ __global__ __launch_bounds__(kBlock) void ct_step_kernel(GwState st,
             done[e] = dn;
         } else {
             k_steps = 1;
-            const double slot = c.slot, dr = c.data_rate, br = c.bit_rate;
-            const double hd = c.hdr_dur, hdr_bits = c.hdr_bits, max_ber = c.max_ber;
+            const StepMath m(c);
+            const double slot = c.slot, br = c.bit_rate;
+            const double hd = c.hdr_dur, hdr_bits = c.hdr_bits;
             const double interval = c.counter_interval;
             const uint32_t bound = (uint32_t)c.counter_bound;
             const uint32_t base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
@@ -113,14 +113,14 @@ __global__ __launch_bounds__(kBlock) void ct_step_kernel(GwState st,
 
             // ---- A.1 / A.2: announcement ---------------------------------------------
             const int L = ndigits(slots);
-            const double pd_a = (double)(L * 8) / dr;
-            const TxTimes an = tx_times(t_a, slot, hd, pd_a);
+            const double pd_a = m.over_rate((double)(L * 8));
+            const TxTimes an = tx_times(m, t_a, hd, pd_a);
             k.tx++;
             uint8_t s_d = st.rxs[(int64_t)d * N + e];
             const uint8_t s_d_old = s_d;
             s_d = st.trans[((int64_t)d * R + RRM) * S + s_d];
             const double ber_a = st.ber[((int64_t)d * R + RRM) * S + s_d];
-            const bool granted = receive(ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, max_ber, fl);
+            const bool granted = receive(m, ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, fl);
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
@@ -155,19 +155,19 @@ __global__ __launch_bounds__(kBlock) void ct_step_kernel(GwState st,
                         } else break;
                     }
                     const uint32_t s = rd.base[rd.head];
-                    const double need = (double)(s * 8u) / dr;           // messages.py:67-75
+                    const double need = m.over_rate((double)(s * 8u));    // messages.py:67-75
                     if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
                     rd.head = (rd.head + 1) & GW_RING_MASK;               // :425
                     rd.len--;
                     k.pop++;
                     const int pay = (int)s - mh;
-                    const TxTimes x = tx_times(cur, slot, hd, (double)(pay * 8) / dr);
+                    const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
                     k.tx++;
                     n_data++;
                     if (!s_r_loaded) { s_r = st.rxs[(int64_t)RRM * N + e]; s_r_old = s_r; s_r_loaded = true; }
                     s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
                     const double ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
-                    const bool ok = receive(ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, max_ber, fl);
+                    const bool ok = receive(m, ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl);
                     if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
                         k.deliv++;
                         rvm |= (1u << d);
@@ -314,12 +314,13 @@ int gw_launch_reset(const GwState& st, const uint8_t* mask, int32_t* obs, void* 
 int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* duration,
                    int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
-    const unsigned grid = (unsigned)((st.N + kBlock - 1) / kBlock);
+    const unsigned blk = (unsigned)st.block;
+    const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
     if (st.pe_stats)
-        hipLaunchKernelGGL(ct_step_kernel<true>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(ct_step_kernel<true>, dim3(grid), dim3(blk), 0, (hipStream_t)stream,
                            st, device, duration, obs, reward, done);
     else
-        hipLaunchKernelGGL(ct_step_kernel<false>, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(ct_step_kernel<false>, dim3(grid), dim3(blk), 0, (hipStream_t)stream,
                            st, device, duration, obs, reward, done);
     return check_launch();
 }

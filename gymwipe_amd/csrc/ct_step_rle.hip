@@ -23,18 +23,16 @@ using namespace gwk;
 
 namespace {
 
-constexpr int kBlock = 64;
-
 template <int DT, bool PER_ENV_STATS>
-__global__ __launch_bounds__(kBlock) void ct_step_rle_kernel(GwState st,
-                                                            const int32_t* __restrict__ device,
-                                                            const int32_t* __restrict__ duration,
-                                                            int32_t* __restrict__ obs,
-                                                            float* __restrict__ reward,
-                                                            uint8_t* __restrict__ done)
+__global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
+                                                         const int32_t* __restrict__ device,
+                                                         const int32_t* __restrict__ duration,
+                                                         int32_t* __restrict__ obs,
+                                                         float* __restrict__ reward,
+                                                         uint8_t* __restrict__ done)
 {
     const int64_t N = st.N;
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const GwDevConst& c = *st.cst;
     const int D = DT > 0 ? DT : c.D;
     const int R = D + 1, S = c.S, RRM = D;
@@ -61,37 +59,43 @@ __global__ __launch_bounds__(kBlock) void ct_step_rle_kernel(GwState st,
             done[e] = dn;
         } else {
             k_steps = 1;
-            const double slot = c.slot, dr = c.data_rate, br = c.bit_rate;
-            const double hd = c.hdr_dur, hdr_bits = c.hdr_bits, max_ber = c.max_ber;
+            const StepMath m(c);
+            const double slot = c.slot, br = c.bit_rate;
+            const double hd = c.hdr_dur, hdr_bits = c.hdr_bits;
             const double interval = c.counter_interval;
             const uint32_t bound = (uint32_t)c.counter_bound;
             const uint32_t base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
             const int mh = c.mac_hdr;
+            const bool idem = c.idem_states != 0;
 
-            // ---- every load of the step is issued here, before anything is stored -------------
+            // ---- every load of the step is issued up here, before anything is stored ------------
             const double t_a = st.now[e];
             const double wake0 = st.wake[e];
             const uint32_t ctr0 = st.counter[e];
             const uint4* rq4 = reinterpret_cast<const uint4*>(st.rq);
             const uint4 wd = rq4[(int64_t)d * N + e];
             uint4 wi[DT > 0 ? DT : 1];
+            uint8_t sj[DT > 0 ? DT : 1];
             if (DT > 0) {
 #pragma unroll
-                for (int i = 0; i < DT; ++i) wi[i] = rq4[(int64_t)i * N + e];
+                for (int i = 0; i < DT; ++i) { wi[i] = rq4[(int64_t)i * N + e]; sj[i] = st.rxs[(int64_t)i * N + e]; }
             }
-            uint8_t s_d = st.rxs[(int64_t)d * N + e];
-            uint8_t s_r = st.rxs[(int64_t)RRM * N + e];
-            const uint8_t s_d_old = s_d, s_r_old = s_r;
+            const uint8_t s_d_old = st.rxs[(int64_t)d * N + e];
+            const uint8_t s_r_old = st.rxs[(int64_t)RRM * N + e];
+            // what the addressed sender / the RRM become after hearing the RRM / sender d once
+            const uint8_t s_d = st.trans[((int64_t)d * R + RRM) * S + s_d_old];
+            const double ber_a = st.ber[((int64_t)d * R + RRM) * S + s_d];
+            uint8_t s_r = s_r_old;
+            const uint8_t s_r1 = st.trans[((int64_t)RRM * R + d) * S + s_r_old];
+            const double ber_x1 = st.ber[((int64_t)RRM * R + d) * S + s_r1];
 
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
             // ---- A.1 / A.2: announcement ------------------------------------------------------
             const int L = ndigits(slots);
-            const TxTimes an = tx_times(t_a, slot, hd, (double)(L * 8) / dr);
+            const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(L * 8)));
             k.tx++;
-            s_d = st.trans[((int64_t)d * R + RRM) * S + s_d];
-            const double ber_a = st.ber[((int64_t)d * R + RRM) * S + s_d];
-            const bool granted = receive(ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, max_ber, fl);
+            const bool granted = receive(m, ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, fl);
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
@@ -104,12 +108,19 @@ __global__ __launch_bounds__(kBlock) void ct_step_rle_kernel(GwState st,
             uint32_t n_ticks = 0;
             int n_data = 0;
 
-            // one counter tick of sender d at time `wake`
-            auto tick_d = [&]() {
-                rq_append(qd, ctr, 1u, mult_d, bound, k);
-                if (ctr < bound) ctr++;
-                wake = wake + interval;                                   // running sum, not k*dt
-                n_ticks++;
+            // all counter ticks of sender d with wake < t (or <= t): counted in f64, appended as one run
+            auto ticks_to = [&](double t, bool inclusive) {
+                uint32_t kk = 0;
+                while (wake < t || (inclusive && wake == t)) {
+                    if (wake == t) fl |= GW_FLAG_TIE;
+                    wake = wake + interval;                               // running sum, not k*dt
+                    kk++;
+                }
+                if (kk) {
+                    rq_bulk(qd, ctr, kk, mult_d, bound, k);
+                    ctr = gw_min_u32(ctr + kk, bound);
+                    n_ticks += kk;
+                }
             };
 
             if (granted) {
@@ -117,41 +128,68 @@ __global__ __launch_bounds__(kBlock) void ct_step_rle_kernel(GwState st,
                 const double stopw = t_r + total;                        // :401 (== timeout time :406)
                 double cur = t_r;
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
-                while (wake < cur) tick_d();
+                ticks_to(cur, false);
                 for (;;) {
                     if (qd.len == 0) {                                    // :409-416
-                        if (wake < stopw) { cur = wake; tick_d(); }
-                        else break;
+                        if (wake < stopw) {
+                            cur = wake;
+                            rq_append(qd, ctr, 1u, mult_d, bound, k);
+                            if (ctr < bound) ctr++;
+                            wake = wake + interval;
+                            n_ticks++;
+                        } else break;
                     }
                     const uint32_t s = base_bytes + rq_head_value(qd);
-                    const double need = (double)(s * 8u) / dr;           // messages.py:67-75
+                    const double need = m.over_rate((double)(s * 8u));    // messages.py:67-75
                     if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
                     rq_consume(qd, 1u, mult_d, bound);                    // :425
                     k.pop++;
                     const int pay = (int)s - mh;
-                    const TxTimes x = tx_times(cur, slot, hd, (double)(pay * 8) / dr);
+                    const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
                     k.tx++;
                     n_data++;
-                    s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
-                    const double ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
-                    const bool ok = receive(ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, max_ber, fl);
+                    double ber_x = ber_x1;
+                    if (idem) {
+                        s_r = s_r1;
+                    } else {
+                        s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
+                        ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
+                    }
+                    const bool ok = receive(m, ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl);
                     if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
                         k.deliv++;
                         rvm |= (1u << d);
                         if (pv == c.counter_bound) dn = 1;
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
-                    // ticks are older events than the MAC's resume at t_e: they go first
-                    while (wake <= x.t_e) { if (wake == x.t_e) fl |= GW_FLAG_TIE; tick_d(); }
+                    ticks_to(x.t_e, true);                                // ticks are older events than the MAC's resume
                     cur = x.t_e;
                     if (!(cur < stopw)) break;                            // window timeout already processed
                 }
             }
 
             // ---- A.5: remaining ticks up to the end of the step -------------------------------
-            while (wake <= t_end) { if (wake == t_end) fl |= GW_FLAG_TIE; tick_d(); }
-            { uint4 o; o.w = 0u; rq_pack(qd, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)d * N + e] = o; }
+            ticks_to(t_end, true);
 
+            // ---- rx-power state of the radios that only listened (simple_stack.py:130-157) -----
+            // (table lookups: still loads, so they come before the first store)
+            auto heard = [&](int j, uint8_t s0) {
+                uint8_t s = st.trans[((int64_t)j * R + RRM) * S + s0];
+                for (int n = 0; n < n_data; ++n) {
+                    const uint8_t s2 = st.trans[((int64_t)j * R + d) * S + s];
+                    if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
+                    s = s2;
+                }
+                return s;
+            };
+            uint8_t sn[DT > 0 ? DT : 1];
+            if (DT > 0) {
+#pragma unroll
+                for (int j = 0; j < DT; ++j) sn[j] = heard(j, sj[j]);
+            }
+
+            // ---- stores ------------------------------------------------------------------------
+            { uint4 o; o.w = 0u; rq_pack(qd, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)d * N + e] = o; }
             // every other sender saw the same n_ticks ticks, values ctr0, ctr0+1, ...
             if (DT > 0) {
 #pragma unroll
@@ -161,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void ct_step_rle_kernel(GwState st,
                     rq_unpack(qi, wi[i].x, wi[i].y, wi[i].z, st.rmid + (((int64_t)e * D + i) << 7));
                     rq_bulk(qi, ctr0, n_ticks, (uint32_t)c.mult[i], bound, k);
                     { uint4 o; o.w = 0u; rq_pack(qi, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)i * N + e] = o; }
+                    if (sn[i] != sj[i]) st.rxs[(int64_t)i * N + e] = sn[i];
                 }
             } else {
                 for (int i = 0; i < D; ++i) {
@@ -170,24 +209,13 @@ __global__ __launch_bounds__(kBlock) void ct_step_rle_kernel(GwState st,
                     rq_unpack(qi, wq.x, wq.y, wq.z, st.rmid + (((int64_t)e * D + i) << 7));
                     rq_bulk(qi, ctr0, n_ticks, (uint32_t)c.mult[i], bound, k);
                     { uint4 o; o.w = 0u; rq_pack(qi, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)i * N + e] = o; }
+                    const uint8_t s0 = st.rxs[(int64_t)i * N + e];
+                    const uint8_t s1 = heard(i, s0);
+                    if (s1 != s0) st.rxs[(int64_t)i * N + e] = s1;
                 }
             }
-
-            // ---- rx-power state of every radio (simple_stack.py:130-157) --------------------------
             if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
             if (s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
-            for (int j = 0; j < D; ++j) {
-                if (j == d) continue;
-                uint8_t s = st.rxs[(int64_t)j * N + e];
-                const uint8_t s0 = s;
-                s = st.trans[((int64_t)j * R + RRM) * S + s];
-                for (int n = 0; n < n_data; ++n) {
-                    const uint8_t s2 = st.trans[((int64_t)j * R + d) * S + s];
-                    if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
-                    s = s2;
-                }
-                if (s != s0) st.rxs[(int64_t)j * N + e] = s;
-            }
 
             // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
@@ -223,12 +251,13 @@ template <int DT>
 int launch(const GwState& st, const int32_t* device, const int32_t* duration,
            int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
-    const unsigned grid = (unsigned)((st.N + kBlock - 1) / kBlock);
+    const unsigned blk = (unsigned)st.block;
+    const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
     if (st.pe_stats)
-        hipLaunchKernelGGL((ct_step_rle_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((ct_step_rle_kernel<DT, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
                            st, device, duration, obs, reward, done);
     else
-        hipLaunchKernelGGL((ct_step_rle_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((ct_step_rle_kernel<DT, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
                            st, device, duration, obs, reward, done);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }

@@ -4,6 +4,7 @@
 // entry point fails with GW_ENODEVICE.
 #include "gw_internal.h"
 #include "gw_rle.h"
+#include "gw_fastmath.h"
 
 #include <hip/hip_runtime.h>
 
@@ -96,6 +97,33 @@ int validate(const gw_config& c)
     if ((int64_t)c.max_duration * c.duration_factor > 100000000)
         return fail(GW_EINVAL, "max_duration*duration_factor too large");
     return GW_OK;
+}
+
+// exact fast paths (gw_fastmath.h): enabled only when validated for THIS configuration
+void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevConst& k)
+{
+    const gw_config* cfg = &cfg_ref;
+    const int R = tab.R;
+    k.inv_slot = 1.0 / cfg->slot;
+    k.rcp_data_rate = 1.0 / tab.data_rate;
+    k.fmod_limit = 0.0;
+    const bool no_fast = getenv("GW_NO_FASTMATH") != nullptr;
+    k.fast_fmod = (!no_fast && gw_fast_fmod_ok(cfg->slot, &k.fmod_limit)) ? 1 : 0;
+    const int64_t max_bytes = (int64_t)cfg->mac_header_bytes + cfg->net_header_bytes + cfg->counter_bound + 64;
+    k.fast_div = (!no_fast && gw_fast_div_ok(tab.data_rate, max_bytes)) ? 1 : 0;
+    // round(err)/bits <= 0.25  <=>  4*round(err) <= bits  when bits is an integer (both < 2^53)
+    k.fast_decide = (!no_fast && cfg->max_ber == 0.25 && tab.coded_factor * 8.0 == floor(tab.coded_factor * 8.0)) ? 1 : 0;
+    k.idem_states = 1;                              // hearing the same talker twice changes nothing more
+    for (int to = 0; to < R && k.idem_states; ++to)
+        for (int from = 0; from < R && k.idem_states; ++from) {
+            if (to == from) continue;
+            for (int s = 0; s < tab.nstates[to]; ++s) {
+                const uint8_t s1 = tab.trans[((size_t)to * R + from) * GW_MAX_NSTATES + s];
+                const uint8_t s2 = tab.trans[((size_t)to * R + from) * GW_MAX_NSTATES + s1];
+                if (s1 != s2) { k.idem_states = 0; break; }
+            }
+        }
+
 }
 
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
@@ -241,8 +269,15 @@ int gw_create(const gw_config* cfg, gw_env** out)
         k.hdr_bits = hb * env->tab.coded_factor;    // physical.py:259
     }
 
+    set_fast_paths(*cfg, env->tab, k);
+
     GwState& st = env->st;
     st.N = N; st.D = D; st.R = R;
+    {
+        const char* kb = getenv("GW_BLOCK");        // tuning knob: threads per workgroup of the step kernel
+        st.block = kb ? atoi(kb) : 64;
+        if (st.block != 16 && st.block != 32 && st.block != 64 && st.block != 128 && st.block != 256) st.block = 64;
+    }
     GwDevConst* d_cst = nullptr; uint8_t* d_trans = nullptr; double* d_ber = nullptr;
     const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
 #define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
@@ -255,7 +290,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
     TRY_ALLOC(st.rxs, N * R);  TRY_ALLOC(st.flags, N);
     if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
-    st.n_slots = (N + 63) / 64;
+    st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
     TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
     TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount);  TRY_ALLOC(d_ber, tcount);
 #undef TRY_ALLOC
@@ -381,6 +416,27 @@ int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values)
     *count = env->tab.nstates[radio];
     if (values) for (int i = 0; i < GW_MAX_NSTATES; ++i) values[i] = i < *count ? env->tab.state_val[radio][i] : 0.0;
     return GW_OK;
+}
+
+// Host-only: which exact fast paths gw_create would enable for cfg (bit 0 fmod, 1 division,
+// 2 decision, 3 idempotent noise states), and the number of noise states per radio.
+int gw_selftest_fastmath(const gw_config* cfg, int32_t* max_noise_states)
+{
+    if (!cfg) return fail(GW_EINVAL, "cfg is NULL");
+    int rc = validate(*cfg);
+    if (rc) return rc;
+    GwHostTables* tab = new GwHostTables();
+    char msg[256] = "";
+    rc = gw_build_tables(*cfg, *tab, msg, sizeof msg);
+    if (rc) { delete tab; return fail(rc, "%s", msg); }
+    GwDevConst k;
+    memset(&k, 0, sizeof k);
+    set_fast_paths(*cfg, *tab, k);
+    int mx = 0;
+    for (int r = 0; r < tab->R; ++r) mx = tab->nstates[r] > mx ? tab->nstates[r] : mx;
+    if (max_noise_states) *max_noise_states = mx;
+    delete tab;
+    return (k.fast_fmod ? 1 : 0) | (k.fast_div ? 2 : 0) | (k.fast_decide ? 4 : 0) | (k.idem_states ? 8 : 0);
 }
 
 // Host-only fuzz of the run-length queue (gw_rle.h, the same code the kernel runs) against an

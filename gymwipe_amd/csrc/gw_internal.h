@@ -18,12 +18,18 @@ struct GwDevConst {
     double  slot, data_rate, bit_rate, coded_factor, max_ber, counter_interval;
     double  hdr_dur;                    // (mac_hdr*8)/data_rate
     double  hdr_bits;                   // (mac_hdr*8)*coded_factor
+    // exact fast paths, each validated on the host at gw_create (gw_fastmath.h); 0 = use the plain form
+    double  inv_slot;                   // RN(1/slot)
+    double  fmod_limit;                 // fast fmod is used for t < fmod_limit
+    double  rcp_data_rate;              // RN(1/data_rate)
+    int32_t fast_fmod, fast_div, fast_decide, idem_states;
 };
 
 // Per-handle device state (structure of arrays; N = num_envs, D senders, R = D+1 radios).
 struct GwState {
     int64_t   N;
     int32_t   D, R;     // host-side copies of the constants (launch sizing)
+    int32_t   block;    // threads per workgroup of the step kernel
     double*   now;        // [N]        simulated time (SimMan.now)
     double*   wake;       // [N]        next counter tick (all senders tick in lock-step)
     uint32_t* counter;    // [N]        sender.counter (identical for all senders of an env)

@@ -149,6 +149,11 @@ int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values_m
  * against an explicit deque(maxlen=100).  Returns the number of mismatches (0 = identical). */
 int gw_selftest_rle(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);
 
+/* Host-only: bit mask of the exact arithmetic fast paths gw_create enables for cfg after validating
+ * them (1 slot remainder, 2 division by the data rate, 4 integer decode decision, 8 idempotent
+ * noise-state map); negative on error.  max_noise_states may be NULL. */
+int gw_selftest_fastmath(const gw_config* cfg, int32_t* max_noise_states);
+
 #ifdef __cplusplus
 }
 #endif

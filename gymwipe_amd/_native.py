@@ -24,7 +24,7 @@ CFG_EXPLICIT_QUEUE = 2
 EXPORTS = (
     "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
     "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_get_state",
-    "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_rle",
+    "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue",
     "gw_selftest_fastmath",
 )
 
@@ -118,7 +118,7 @@ def lib():
     L.gw_link_info.restype = C.c_int
     L.gw_noise_states.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_double)]
     L.gw_noise_states.restype = C.c_int
-    L.gw_selftest_rle.argtypes, L.gw_selftest_rle.restype = [C.c_uint64, i32, i32, i32], C.c_int
+    L.gw_selftest_queue.argtypes, L.gw_selftest_queue.restype = [C.c_uint64, i32, i32, i32], C.c_int
     L.gw_selftest_fastmath.argtypes = [C.POINTER(Config), C.POINTER(i32)]
     L.gw_selftest_fastmath.restype = C.c_int
     if L.gw_abi_version() != ABI_VERSION:

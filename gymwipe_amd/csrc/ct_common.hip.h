@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gw_internal.h"
-#include "gw_rle.h"
+#include "gw_queue.h"
 #include "gw_fastmath.h"
 
 namespace gwk {

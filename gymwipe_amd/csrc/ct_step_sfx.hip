@@ -1,30 +1,25 @@
-// ct_step_rle.hip -- the default step kernel: MAC queues held as runs of counter ticks.
+// ct_step_sfx.hip -- the default step kernel.  MAC queues in the "suffix" encoding of gw_queue.h:
+// one length byte per sender, a tick counter and the reset breakpoints per env.  A counter tick is
+// `len = min(len + mult, 100)`, a pop is `len -= 1`, the head packet's size is arithmetic on the tick
+// index -- no queue memory is touched by the step at all, so the kernel issues every load up front,
+// walks the step's event horizon in registers, and stores once.
 //
-// Why: in CounterTraffic every packet a sender enqueues at a counter tick has size
-// 25 + c bytes, `mult` copies per tick, and c advances by one per tick until it
-// saturates at COUNTER_BOUND (counter_traffic.py:53-61).  A queue is therefore a short
-// list of runs (c_first, n_ticks) -- a new run starts only after a reset() -- plus how
-// many packets of the head tick are already gone.  deque(maxlen=100).append
-// (simple_stack.py:361,469) keeps "the last 100 of old ++ new", which is closed-form on
-// runs.  So a tick is a register increment instead of `mult` scattered 4-byte stores,
-// the window loop (simple_stack.py:397-434) never loads from memory after a store, and
-// per (sender, env) one 16-byte word {meta, head run, tail run} is loaded and stored.
-// The encoding is exact: gw_get_state("queue") expands it and the tests compare that
-// with the oracle's explicit deque element by element.
-//
-// Layout per (sender i, env e): rq[(i*N + e)*4 + {0,1,2}] = meta, head run, tail run
-//   nruns == 0: empty.  nruns == 1: the only run is the TAIL word.  nruns >= 2: head and
-//   tail words plus nruns-2 middle runs in rmid[e][i][(mhead + j) & 127].
-//   The head run is kept normalised: its first tick is the queue's head tick.
+// Step walk, reference file:line as in ct_common.hip.h / ct_step.hip:
+//   A.1  t_s = t_a + (slot - t_a % slot)                                   simtools.py:44-53
+//   A.2  announcement heard by the addressed sender (header, payload)      simple_stack.py:214-286,536-558
+//   A.3  window: pop + transmit while (stop - now) > bits/dataRate         simple_stack.py:397-434
+//   A.4  RRM decodes each data packet -> interpreter                       networking/devices.py:163-168
+//   A.5  t_end = t_r + (slots+1)*slot; ticks every 1 ms (running f64 sum)   counter_traffic.py:53-61
+//   A.6  equal-time events: earlier-inserted first; process initialisation URGENT.
 #include "ct_common.hip.h"
-#include "gw_rle.h"
+#include "gw_queue.h"
 
 using namespace gwk;
 
 namespace {
 
 template <int DT, bool PER_ENV_STATS>
-__global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
+__global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
                                                          const int32_t* __restrict__ device,
                                                          const int32_t* __restrict__ duration,
                                                          int32_t* __restrict__ obs,
@@ -70,15 +65,17 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
 
             // ---- every load of the step is issued up here, before anything is stored ------------
             const double t_a = st.now[e];
-            const double wake0 = st.wake[e];
-            const uint32_t ctr0 = st.counter[e];
-            const uint4* rq4 = reinterpret_cast<const uint4*>(st.rq);
-            const uint4 wd = rq4[(int64_t)d * N + e];
-            uint4 wi[DT > 0 ? DT : 1];
-            uint8_t sj[DT > 0 ? DT : 1];
+            double wake = st.wake[e];
+            const uint32_t tau0 = st.tau[e];
+            const uint32_t nbp = st.nbp[e];
+            const GwBp bpc = st.bpc[e];
+            const GwBp bpp = st.bpp[e];
+            const GwBp* hist = st.bph + ((int64_t)e << 7);
+            uint32_t len_d = st.qlen[(int64_t)d * N + e];
+            uint8_t li[DT > 0 ? DT : 1], sj[DT > 0 ? DT : 1];
             if (DT > 0) {
 #pragma unroll
-                for (int i = 0; i < DT; ++i) { wi[i] = rq4[(int64_t)i * N + e]; sj[i] = st.rxs[(int64_t)i * N + e]; }
+                for (int i = 0; i < DT; ++i) { li[i] = st.qlen[(int64_t)i * N + e]; sj[i] = st.rxs[(int64_t)i * N + e]; }
             }
             const uint8_t s_d_old = st.rxs[(int64_t)d * N + e];
             const uint8_t s_r_old = st.rxs[(int64_t)RRM * N + e];
@@ -88,6 +85,8 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
             uint8_t s_r = s_r_old;
             const uint8_t s_r1 = st.trans[((int64_t)RRM * R + d) * S + s_r_old];
             const double ber_x1 = st.ber[((int64_t)RRM * R + d) * S + s_r1];
+            const uint32_t mult_d = (uint32_t)c.mult[d];
+            const uint32_t inv16_d = c.inv16[d];
 
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
@@ -100,15 +99,11 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
             // ---- A.3: window at sender d ------------------------------------------------------
-            RQ qd;
-            rq_unpack(qd, wd.x, wd.y, wd.z, st.rmid + (((int64_t)e * D + d) << 7));
-            const uint32_t mult_d = (uint32_t)c.mult[d];
-            double wake = wake0;
-            uint32_t ctr = ctr0;
-            uint32_t n_ticks = 0;
+            uint32_t tau = tau0;
             int n_data = 0;
+            Tally kd = {0, 0, 0, 0, 0};                                   // appends/drops of sender d only
 
-            // all counter ticks of sender d with wake < t (or <= t): counted in f64, appended as one run
+            // all counter ticks with wake < t (or <= t): counted in f64, applied to d's queue length
             auto ticks_to = [&](double t, bool inclusive) {
                 uint32_t kk = 0;
                 while (wake < t || (inclusive && wake == t)) {
@@ -116,11 +111,8 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
                     wake = wake + interval;                               // running sum, not k*dt
                     kk++;
                 }
-                if (kk) {
-                    rq_bulk(qd, ctr, kk, mult_d, bound, k);
-                    ctr = gw_min_u32(ctr + kk, bound);
-                    n_ticks += kk;
-                }
+                tau += kk;
+                len_d = gw_len_after_ticks(len_d, kk, mult_d, kd);
             };
 
             if (granted) {
@@ -130,19 +122,19 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
                 ticks_to(cur, false);
                 for (;;) {
-                    if (qd.len == 0) {                                    // :409-416
+                    if (len_d == 0) {                                     // :409-416
                         if (wake < stopw) {
                             cur = wake;
-                            rq_append(qd, ctr, 1u, mult_d, bound, k);
-                            if (ctr < bound) ctr++;
                             wake = wake + interval;
-                            n_ticks++;
+                            tau++;
+                            len_d = gw_len_after_ticks(0u, 1u, mult_d, kd);
                         } else break;
                     }
-                    const uint32_t s = base_bytes + rq_head_value(qd);
+                    const uint32_t age = gw_ceil_div(len_d, mult_d, inv16_d);
+                    const uint32_t s = base_bytes + gw_tick_value(tau - age, bpc, bpp, nbp, hist, bound);
                     const double need = m.over_rate((double)(s * 8u));    // messages.py:67-75
                     if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
-                    rq_consume(qd, 1u, mult_d, bound);                    // :425
+                    len_d--;                                              // :425
                     k.pop++;
                     const int pay = (int)s - mh;
                     const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
@@ -170,9 +162,12 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
 
             // ---- A.5: remaining ticks up to the end of the step -------------------------------
             ticks_to(t_end, true);
+            const uint32_t n_ticks = tau - tau0;
+            k.app += kd.app;
+            k.drop += kd.drop;
 
             // ---- rx-power state of the radios that only listened (simple_stack.py:130-157) -----
-            // (table lookups: still loads, so they come before the first store)
+            // (table lookups are loads too: they come before the first store)
             auto heard = [&](int j, uint8_t s0) {
                 uint8_t s = st.trans[((int64_t)j * R + RRM) * S + s0];
                 for (int n = 0; n < n_data; ++n) {
@@ -189,28 +184,22 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
             }
 
             // ---- stores ------------------------------------------------------------------------
-            { uint4 o; o.w = 0u; rq_pack(qd, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)d * N + e] = o; }
-            // every other sender saw the same n_ticks ticks, values ctr0, ctr0+1, ...
+            st.qlen[(int64_t)d * N + e] = (uint8_t)len_d;
+            // every other sender saw the same n_ticks ticks
             if (DT > 0) {
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
                     if (i == d) continue;
-                    RQ qi;
-                    rq_unpack(qi, wi[i].x, wi[i].y, wi[i].z, st.rmid + (((int64_t)e * D + i) << 7));
-                    rq_bulk(qi, ctr0, n_ticks, (uint32_t)c.mult[i], bound, k);
-                    { uint4 o; o.w = 0u; rq_pack(qi, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)i * N + e] = o; }
+                    st.qlen[(int64_t)i * N + e] = (uint8_t)gw_len_after_ticks(li[i], n_ticks, (uint32_t)c.mult[i], k);
                     if (sn[i] != sj[i]) st.rxs[(int64_t)i * N + e] = sn[i];
                 }
             } else {
                 for (int i = 0; i < D; ++i) {
                     if (i == d) continue;
-                    RQ qi;
-                    const uint4 wq = rq4[(int64_t)i * N + e];
-                    rq_unpack(qi, wq.x, wq.y, wq.z, st.rmid + (((int64_t)e * D + i) << 7));
-                    rq_bulk(qi, ctr0, n_ticks, (uint32_t)c.mult[i], bound, k);
-                    { uint4 o; o.w = 0u; rq_pack(qi, o.x, o.y, o.z); reinterpret_cast<uint4*>(st.rq)[(int64_t)i * N + e] = o; }
+                    const uint32_t l0 = st.qlen[(int64_t)i * N + e];
                     const uint8_t s0 = st.rxs[(int64_t)i * N + e];
                     const uint8_t s1 = heard(i, s0);
+                    st.qlen[(int64_t)i * N + e] = (uint8_t)gw_len_after_ticks(l0, n_ticks, (uint32_t)c.mult[i], k);
                     if (s1 != s0) st.rxs[(int64_t)i * N + e] = s1;
                 }
             }
@@ -229,7 +218,7 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
 
             st.now[e] = t_end;
             st.wake[e] = wake;
-            st.counter[e] = ctr;
+            st.tau[e] = tau;
             st.rvmask[e] = rvm;
             st.last_abs[e] = last_abs;
             st.done[e] = dn;
@@ -247,6 +236,37 @@ __global__ __launch_bounds__(256) void ct_step_rle_kernel(GwState st,
     publish_totals(st.totals, k, k_steps, k_bad, fl_new);
 }
 
+// counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound.
+// In the suffix encoding "counters <- 0" is a new breakpoint (tau, 0).
+__global__ void ct_reset_sfx_kernel(GwState st, const uint8_t* __restrict__ mask, int32_t* __restrict__ obs)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= st.N) return;
+    if (!mask || mask[e]) {
+        const uint32_t tau = st.tau[e];
+        const uint32_t n = st.nbp[e];
+        GwBp cur = st.bpc[e];
+        if (cur.t0 == tau) {                       // no tick since the last breakpoint: overwrite it
+            cur.c0 = 0u;
+            st.bpc[e] = cur;
+            st.bph[((int64_t)e << 7) + ((n - 1u) & GW_RING_MASK)] = cur;
+        } else {
+            st.bpp[e] = cur;
+            cur.t0 = tau; cur.c0 = 0u;
+            st.bpc[e] = cur;
+            st.bph[((int64_t)e << 7) + (n & GW_RING_MASK)] = cur;
+            st.nbp[e] = n + 1u;
+        }
+        st.rvmask[e] = 0u;
+        st.last_abs[e] = 0;
+        st.done[e] = 0;
+    }
+    if (obs) {
+        const uint32_t rvm = st.rvmask[e];
+        obs[e] = st.cst->payload_value * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u)) + st.cst->counter_bound;
+    }
+}
+
 template <int DT>
 int launch(const GwState& st, const int32_t* device, const int32_t* duration,
            int32_t* obs, float* reward, uint8_t* done, void* stream)
@@ -254,23 +274,31 @@ int launch(const GwState& st, const int32_t* device, const int32_t* duration,
     const unsigned blk = (unsigned)st.block;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
     if (st.pe_stats)
-        hipLaunchKernelGGL((ct_step_rle_kernel<DT, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
                            st, device, duration, obs, reward, done);
     else
-        hipLaunchKernelGGL((ct_step_rle_kernel<DT, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
                            st, device, duration, obs, reward, done);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
 } // namespace
 
-int gw_launch_step_rle(const GwState& st, const int32_t* device, const int32_t* duration,
+int gw_launch_step_sfx(const GwState& st, const int32_t* device, const int32_t* duration,
                        int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
     switch (st.D) {
     case 2:  return launch<2>(st, device, duration, obs, reward, done, stream);
     case 4:  return launch<4>(st, device, duration, obs, reward, done, stream);
     case 8:  return launch<8>(st, device, duration, obs, reward, done, stream);
+    case 16: return launch<16>(st, device, duration, obs, reward, done, stream);
     default: return launch<0>(st, device, duration, obs, reward, done, stream);
     }
+}
+
+int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + 255) / 256);
+    hipLaunchKernelGGL(ct_reset_sfx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, mask, obs);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }

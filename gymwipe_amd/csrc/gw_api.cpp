@@ -3,7 +3,7 @@
 // There is deliberately no CPU fallback: without a HIP device every compute
 // entry point fails with GW_ENODEVICE.
 #include "gw_internal.h"
-#include "gw_rle.h"
+#include "gw_queue.h"
 #include "gw_fastmath.h"
 
 #include <hip/hip_runtime.h>
@@ -91,8 +91,6 @@ int validate(const gw_config& c)
         for (int i = 0; i < c.num_devices; ++i)
             if (c.mult[i] > GW_MAX_MULT)
                 return fail(GW_EUNSUPPORTED, "mult[%d] > %d needs GW_CFG_EXPLICIT_QUEUE", i, GW_MAX_MULT);
-        if (c.counter_bound > 0x1ffff - 1)
-            return fail(GW_EUNSUPPORTED, "counter_bound > 131070 needs GW_CFG_EXPLICIT_QUEUE");
     }
     if ((int64_t)c.max_duration * c.duration_factor > 100000000)
         return fail(GW_EINVAL, "max_duration*duration_factor too large");
@@ -129,44 +127,20 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
                 int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
-    return env->st.rq ? gw_launch_step_rle(env->st, device, duration, obs, reward, done, stream)
+    return env->st.tau ? gw_launch_step_sfx(env->st, device, duration, obs, reward, done, stream)
                       : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
 
-// Expand the run-length queue {meta, head run, tail run} (+ middle runs) of one (env, sender)
-// into packet byte sizes, head first.  Returns the number of packets or -1 if inconsistent.
-int expand_rle_raw(uint32_t bound, uint32_t base, uint32_t mult, const uint32_t* q4, const uint32_t* mid,
-                   uint32_t* out /* [GW_QUEUE_CAP] */)
+// Expand the suffix-encoded queue of one sender into packet byte sizes, head first (gw_queue.h).
+void expand_sfx(uint32_t bound, uint32_t base, uint32_t mult, uint32_t len, uint32_t tau,
+                GwBp cur, GwBp prev, uint32_t nbp, const GwBp* hist, uint32_t* out /* [GW_QUEUE_CAP] */)
 {
-    const uint32_t meta = q4[0];
-    const uint32_t nruns = GW_META_NRUNS(meta), used = GW_META_USED(meta), len = GW_META_LEN(meta);
-    const uint32_t mhead = GW_META_MHEAD(meta);
-    uint32_t pos = 0;
-    bool first_tick = true;
-    for (uint32_t r = 0; r < nruns; ++r) {
-        uint32_t w;
-        if (r == nruns - 1) w = q4[2];                     // the tail word (also the head when nruns == 1)
-        else if (r == 0) w = q4[1];
-        else w = mid[(mhead + r - 1) & GW_RING_MASK];
-        const uint32_t c0 = GW_RUN_C(w), n = GW_RUN_N(w);
-        for (uint32_t t = 0; t < n; ++t) {
-            const uint32_t v = (c0 + t < bound) ? c0 + t : bound;
-            const uint32_t copies = first_tick ? mult - used : mult;
-            first_tick = false;
-            for (uint32_t m = 0; m < copies; ++m) {
-                if (pos >= GW_QUEUE_CAP) return -1;
-                out[pos++] = base + v;
-            }
-        }
+    // the stream holds mult*tau packets; the queue is its last `len`; packet a sits in tick a / mult
+    const uint64_t total = (uint64_t)mult * tau;
+    for (uint32_t p = 0; p < len; ++p) {
+        const uint64_t a = total - len + p;
+        out[p] = base + gw_tick_value((uint32_t)(a / mult), cur, prev, nbp, hist, bound);
     }
-    return pos == len ? (int)pos : -1;
-}
-
-int expand_rle(const gw_env* env, int sender, const uint32_t* q4, const uint32_t* mid, uint32_t* out)
-{
-    return expand_rle_raw((uint32_t)env->cfg.counter_bound,
-                          (uint32_t)(env->cfg.mac_header_bytes + env->cfg.net_header_bytes),
-                          (uint32_t)env->cfg.mult[sender], q4, mid, out);
 }
 
 } // namespace
@@ -260,7 +234,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     k.counter_bound = cfg->counter_bound; k.payload_value = cfg->payload_value;
     k.mac_hdr = cfg->mac_header_bytes; k.net_hdr = cfg->net_header_bytes;
     k.duration_factor = cfg->duration_factor; k.max_duration = cfg->max_duration;
-    for (int i = 0; i < D; ++i) k.mult[i] = cfg->mult[i];
+    for (int i = 0; i < D; ++i) { k.mult[i] = cfg->mult[i]; k.inv16[i] = (65536u + (uint32_t)cfg->mult[i] - 1u) / (uint32_t)cfg->mult[i]; }
     k.slot = cfg->slot; k.data_rate = env->tab.data_rate; k.bit_rate = cfg->bit_rate;
     k.coded_factor = env->tab.coded_factor; k.max_ber = cfg->max_ber; k.counter_interval = cfg->counter_interval;
     {
@@ -281,11 +255,13 @@ int gw_create(const gw_config* cfg, gw_env** out)
     GwDevConst* d_cst = nullptr; uint8_t* d_trans = nullptr; double* d_ber = nullptr;
     const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
 #define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
-    TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
+    TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);
+    if (cfg->flags & GW_CFG_EXPLICIT_QUEUE) TRY_ALLOC(st.counter, N);
     if (cfg->flags & GW_CFG_EXPLICIT_QUEUE) {
         TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
     } else {
-        TRY_ALLOC(st.rq, N * D * 4);  TRY_ALLOC(st.rmid, N * D * GW_RING_PHYS);
+        TRY_ALLOC(st.qlen, N * D);  TRY_ALLOC(st.tau, N);  TRY_ALLOC(st.nbp, N);
+        TRY_ALLOC(st.bpc, N);       TRY_ALLOC(st.bpp, N);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
     }
     TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
     TRY_ALLOC(st.rxs, N * R);  TRY_ALLOC(st.flags, N);
@@ -302,10 +278,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     HIP_TRY_D(hipMemcpy(d_ber, env->tab.ber, tcount * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
-    if (st.rq) {
-        HIP_TRY_D(hipMemset(st.rq, 0, (size_t)N * D * 4 * sizeof(uint32_t)));
-        HIP_TRY_D(hipMemset(st.rmid, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
-    }
+    if (st.bph) HIP_TRY_D(hipMemset(st.bph, 0, (size_t)N * GW_RING_PHYS * sizeof(GwBp)));
     rc = gw_launch_init(st, nullptr);
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
     HIP_TRY_D(hipDeviceSynchronize());
@@ -328,7 +301,9 @@ int gw_reset(gw_env* env, const uint8_t* mask_dev, int32_t* obs_dev, void* strea
     if (!env) return fail(GW_EINVAL, "env is NULL");
     int rc = select_device(env);
     if (rc) return rc;
-    if (gw_launch_reset(env->st, mask_dev, obs_dev, stream)) return fail(GW_EHIP, "reset kernel launch failed");
+    if (env->st.tau ? gw_launch_reset_sfx(env->st, mask_dev, obs_dev, stream)
+                    : gw_launch_reset(env->st, mask_dev, obs_dev, stream))
+        return fail(GW_EHIP, "reset kernel launch failed");
     return GW_OK;
 }
 
@@ -439,64 +414,68 @@ int gw_selftest_fastmath(const gw_config* cfg, int32_t* max_noise_states)
     return (k.fast_fmod ? 1 : 0) | (k.fast_div ? 2 : 0) | (k.fast_decide ? 4 : 0) | (k.idem_states ? 8 : 0);
 }
 
-// Host-only fuzz of the run-length queue (gw_rle.h, the same code the kernel runs) against an
-// explicit deque(maxlen=GW_QUEUE_CAP): random ticks (single and bulk), resets and pops.
+// Host-only fuzz of the suffix queue encoding (gw_queue.h, the same code the kernel runs) against
+// explicit deque(maxlen=GW_QUEUE_CAP) objects, one per sender: random ticks, resets and pops.
 // Returns the number of mismatching operations (0 = identical), negative on bad arguments.
-int gw_selftest_rle(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound)
+int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound)
 {
-    if (operations < 0 || mult < 1 || mult > GW_MAX_MULT || counter_bound < 1 || counter_bound > 0x1fffe)
-        return fail(GW_EINVAL, "gw_selftest_rle: bad arguments");
+    if (operations < 0 || mult < 1 || mult > GW_MAX_MULT || counter_bound < 1)
+        return fail(GW_EINVAL, "gw_selftest_queue: bad arguments");
     uint64_t x = seed * 6364136223846793005ull + 1442695040888963407ull;
     auto rnd = [&x](uint32_t n) {                      // xorshift64*, test-only
         x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
         return (uint32_t)(((x * 2685821657736338717ull) >> 33) % n);
     };
-    const uint32_t bound = (uint32_t)counter_bound, base = 25u, m = (uint32_t)mult;
-    std::vector<uint32_t> mid(GW_RING_PHYS, 0u);
-    RQ q;
-    rq_unpack(q, 0u, 0u, 0u, mid.data());
-    std::deque<uint32_t> ref;
+    const uint32_t bound = (uint32_t)counter_bound, base = 25u;
+    const uint32_t mults[2] = {(uint32_t)mult, mult > 1 ? 1u : 3u};   // two senders sharing the env's ticks
+    uint32_t inv16[2];
+    for (int i = 0; i < 2; ++i) inv16[i] = (65536u + mults[i] - 1u) / mults[i];
+    std::vector<GwBp> hist(GW_RING_PHYS);
+    GwBp cur = {0u, 1u}, prev = cur;
+    hist[0] = cur;
+    uint32_t nbp = 1, tau = 0, len[2] = {0, 0}, bad = 0, ctr = 1;
+    std::deque<uint32_t> ref[2];
     GwTally tally = {0, 0, 0, 0, 0};
-    uint32_t ctr = 1, bad = 0;
     uint64_t ref_drops = 0;
     for (int32_t op = 0; op < operations; ++op) {
         const uint32_t what = rnd(16);
-        if (what < 9) {                                 // ticks
+        if (what < 9) {                                 // k counter ticks (counter_traffic.py:53-61)
             const uint32_t kk = 1 + rnd(what < 5 ? 3 : 22);
-            const bool bulk = rnd(2) != 0;
-            uint32_t c0 = ctr;
             for (uint32_t t = 0; t < kk; ++t) {
-                for (uint32_t j = 0; j < m; ++j) {
-                    if (ref.size() == GW_QUEUE_CAP) { ref.pop_front(); ++ref_drops; }
-                    ref.push_back(base + ctr);
-                }
-                if (!bulk) rq_append(q, ctr, 1u, m, bound, tally);
+                for (int i = 0; i < 2; ++i)
+                    for (uint32_t j = 0; j < mults[i]; ++j) {
+                        if (ref[i].size() == GW_QUEUE_CAP) { ref[i].pop_front(); ++ref_drops; }
+                        ref[i].push_back(base + ctr);
+                    }
                 if (ctr < bound) ++ctr;
             }
-            if (bulk) rq_bulk(q, c0, kk, m, bound, tally);
-        } else if (what < 11) {                         // reset(): counter_traffic.py:139-140
+            tau += kk;
+            for (int i = 0; i < 2; ++i) len[i] = gw_len_after_ticks(len[i], kk, mults[i], tally);
+        } else if (what < 12) {                         // reset(): counter_traffic.py:139-140
             ctr = 0;
-        } else if (what == 11) {                        // jump close to saturation
-            if (bound > 8 && ctr + 8 < bound && rnd(4) == 0) ctr = bound - 1 - rnd(6);
-        } else {                                        // pops
+            if (cur.t0 == tau) { cur.c0 = 0; hist[(nbp - 1) & GW_RING_MASK] = cur; }
+            else { prev = cur; cur.t0 = tau; cur.c0 = 0; hist[nbp & GW_RING_MASK] = cur; ++nbp; }
+        } else {                                        // pops from one sender
+            const int i = (int)rnd(2);
             uint32_t n = 1 + rnd(what == 15 ? 40 : 4);
-            while (n-- && !ref.empty()) {
-                const uint32_t hv = base + rq_head_value(q);
-                if (hv != ref.front()) ++bad;
-                ref.pop_front();
-                rq_consume(q, 1u, m, bound);
+            while (n-- && !ref[i].empty()) {
+                const uint32_t age = gw_ceil_div(len[i], mults[i], inv16[i]);
+                const uint32_t hv = base + gw_tick_value(tau - age, cur, prev, nbp, hist.data(), bound);
+                if (len[i] != ref[i].size() || hv != ref[i].front()) ++bad;
+                ref[i].pop_front();
+                len[i]--;
             }
         }
-        uint32_t w[3], out[GW_QUEUE_CAP];
-        rq_pack(q, w[0], w[1], w[2]);
-        RQ back;                                        // the packed words must round-trip
-        rq_unpack(back, w[0], w[1], w[2], mid.data());
-        if (back.mhead != q.mhead || back.nruns != q.nruns || back.used != q.used || back.len != q.len ||
-            back.tc != q.tc || back.tn != q.tn || (q.nruns >= 2 && (back.hc != q.hc || back.hn != q.hn))) { ++bad; continue; }
-        const int n = expand_rle_raw(bound, base, m, w, mid.data(), out);
-        bool same = n == (int)ref.size();
-        for (int i = 0; same && i < n; ++i) same = out[i] == ref[(size_t)i];
-        if (!same) ++bad;
+        if (gw_min_u32(cur.c0 + (tau - cur.t0), bound) != ctr) ++bad;       // derived sender.counter
+        for (int i = 0; i < 2; ++i) {
+            uint32_t out[GW_QUEUE_CAP];
+            bool same = len[i] == ref[i].size();
+            if (same) {
+                expand_sfx(bound, base, mults[i], len[i], tau, cur, prev, nbp, hist.data(), out);
+                for (uint32_t p = 0; same && p < len[i]; ++p) same = out[p] == ref[i][p];
+            }
+            if (!same) ++bad;
+        }
     }
     if (tally.drop != ref_drops) ++bad;
     return (int)bad;
@@ -549,26 +528,41 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         }
         return GW_OK;
     }
-    if ((!strcmp(field, "qlen") || !strcmp(field, "queue")) && st.rq) {
-        std::vector<uint32_t> q4((size_t)N * D * 4);
-        HIP_TRY(hipMemcpy(q4.data(), st.rq, q4.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if ((!strcmp(field, "qlen") || !strcmp(field, "queue") || !strcmp(field, "counter")) && st.tau) {
+        std::vector<uint8_t> ql((size_t)N * D);
+        std::vector<uint32_t> tau(N), nbp(N);
+        std::vector<GwBp> cur(N), prev(N);
+        HIP_TRY(hipMemcpy(ql.data(), st.qlen, ql.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tau.data(), st.tau, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(nbp.data(), st.nbp, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cur.data(), st.bpc, N * sizeof(GwBp), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(prev.data(), st.bpp, N * sizeof(GwBp), hipMemcpyDeviceToHost));
+        const uint32_t bound = (uint32_t)env->cfg.counter_bound;
+        if (field[0] == 'c') {                       // sender.counter == value of the next tick
+            NEED(N * D, uint32_t);
+            uint32_t* o = (uint32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) {
+                const uint32_t v = gw_min_u32(cur[e].c0 + (tau[e] - cur[e].t0), bound);
+                for (int i = 0; i < D; ++i) o[e * D + i] = v;
+            }
+            return GW_OK;
+        }
         if (field[1] == 'l') {
             NEED(N * D, int32_t);
             int32_t* o = (int32_t*)dst;
-            for (int64_t e = 0; e < N; ++e)
-                for (int i = 0; i < D; ++i) o[e * D + i] = (int32_t)GW_META_LEN(q4[((size_t)i * N + e) * 4]);
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ql[(size_t)i * N + e];
             return GW_OK;
         }
         NEED(N * D * GW_QUEUE_CAP, uint32_t);
-        std::vector<uint32_t> mid((size_t)N * D * GW_RING_PHYS);
-        HIP_TRY(hipMemcpy(mid.data(), st.rmid, mid.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<GwBp> hist((size_t)N * GW_RING_PHYS);
+        HIP_TRY(hipMemcpy(hist.data(), st.bph, hist.size() * sizeof(GwBp), hipMemcpyDeviceToHost));
         uint32_t* o = (uint32_t*)dst;
         memset(o, 0, bytes);
+        const uint32_t base = (uint32_t)(env->cfg.mac_header_bytes + env->cfg.net_header_bytes);
         for (int64_t e = 0; e < N; ++e)
             for (int i = 0; i < D; ++i)
-                if (expand_rle(env, i, &q4[((size_t)i * N + e) * 4], &mid[((size_t)e * D + i) * GW_RING_PHYS],
-                               o + ((size_t)e * D + i) * GW_QUEUE_CAP) < 0)
-                    return fail(GW_EHIP, "inconsistent run-length queue at env %lld sender %d", (long long)e, i);
+                expand_sfx(bound, base, (uint32_t)env->cfg.mult[i], ql[(size_t)i * N + e], tau[e], cur[e], prev[e],
+                           nbp[e], &hist[(size_t)e * GW_RING_PHYS], o + ((size_t)e * D + i) * GW_QUEUE_CAP);
         return GW_OK;
     }
     if (!strcmp(field, "qlen") || !strcmp(field, "queue")) {

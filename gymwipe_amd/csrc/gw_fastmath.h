@@ -5,7 +5,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
-#include "gw_rle.h"     // GW_HD
+#include "gw_queue.h"   // GW_HD
 
 // t % slot for t >= 0 (simtools.py:53).  q = floor(RN(t * RN(1/slot))) is within +-1 of floor(t/slot)
 // while t/slot < 2^40; the FMA residual t - q*slot is then exactly representable provided the

@@ -19,11 +19,14 @@ struct GwDevConst {
     double  hdr_dur;                    // (mac_hdr*8)/data_rate
     double  hdr_bits;                   // (mac_hdr*8)*coded_factor
     // exact fast paths, each validated on the host at gw_create (gw_fastmath.h); 0 = use the plain form
+    uint32_t inv16[GW_MAX_DEVICES];     // ceil(65536 / mult[i])
     double  inv_slot;                   // RN(1/slot)
     double  fmod_limit;                 // fast fmod is used for t < fmod_limit
     double  rcp_data_rate;              // RN(1/data_rate)
     int32_t fast_fmod, fast_div, fast_decide, idem_states;
 };
+
+struct GwBp { uint32_t t0, c0; };        // counting restarts at tick t0 with counter value c0
 
 // Per-handle device state (structure of arrays; N = num_envs, D senders, R = D+1 radios).
 struct GwState {
@@ -37,9 +40,13 @@ struct GwState {
     //  explicit (GW_CFG_EXPLICIT_QUEUE): a ring of packet byte sizes
     uint16_t* qhl;        // [D][N]     ring head (low byte) | length (high byte)
     uint32_t* ring;       // [N][D][GW_RING_PHYS]  packet byte sizes
-    //  run-length (default): runs of counter ticks, see ct_step_rle.hip
-    uint32_t* rq;         // [D][N][4]  {meta, head run, tail run, spare}; one 16-B load per (sender, env)
-    uint32_t* rmid;       // [N][D][GW_RING_PHYS]  runs strictly between head and tail (touched only after resets)
+    //  suffix (default): see gw_queue.h -- one length byte per sender, tick counter + breakpoints per env
+    uint8_t*  qlen;       // [D][N]     packets in the queue of sender i
+    uint32_t* tau;        // [N]        counter ticks executed so far (index of the next tick)
+    uint32_t* nbp;        // [N]        breakpoints recorded so far
+    GwBp*     bpc;        // [N]        newest breakpoint  (tick, counter value)
+    GwBp*     bpp;        // [N]        second newest
+    GwBp*     bph;        // [N][GW_RING_PHYS]  ring of all breakpoints, entry j at [j & 127]
     uint32_t* rvmask;     // [N]        bit i set <=> receivedValues[i] == payload_value
     int32_t*  last_abs;   // [N]        interpreter._lastAbsDifference
     uint8_t*  done;       // [N]        interpreter._done
@@ -79,20 +86,8 @@ int gw_launch_reset(const GwState& st, const uint8_t* mask, int32_t* obs, void* 
 int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* duration,
                    int32_t* obs, float* reward, uint8_t* done, void* stream);
 int gw_launch_received(const GwState& st, int32_t* out, void* stream);
-int gw_launch_step_rle(const GwState& st, const int32_t* device, const int32_t* duration,
+int gw_launch_step_sfx(const GwState& st, const int32_t* device, const int32_t* duration,
                        int32_t* obs, float* reward, uint8_t* done, void* stream);
+int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
 
-// run-length queue word layout (shared with the host-side reader in gw_api.cpp)
-//   run  : bits 0..16 counter value of the run's first live tick, bits 17..23 number of ticks
-//   meta : bits 0..6 index of the first middle run, 7..13 number of runs, 14..17 packets already
-//          taken from the head tick, 18..24 packets in the queue
-#define GW_RUN_C(w)        ((w) & 0x1ffffu)
-#define GW_RUN_N(w)        (((w) >> 17) & 0x7fu)
-#define GW_RUN_PACK(c, n)  ((uint32_t)(c) | ((uint32_t)(n) << 17))
-#define GW_META_MHEAD(m)   ((m) & 0x7fu)
-#define GW_META_NRUNS(m)   (((m) >> 7) & 0x7fu)
-#define GW_META_USED(m)    (((m) >> 14) & 0xfu)
-#define GW_META_LEN(m)     (((m) >> 18) & 0x7fu)
-#define GW_META_PACK(mhead, nruns, used, len) \
-    ((uint32_t)(mhead) | ((uint32_t)(nruns) << 7) | ((uint32_t)(used) << 14) | ((uint32_t)(len) << 18))
-#define GW_MAX_MULT        15          // packets per tick in the run-length encoding (4-bit field)
+#define GW_MAX_MULT        15          // packets per tick supported by the suffix encoding's ceil-div

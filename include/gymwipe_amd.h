@@ -91,7 +91,7 @@ typedef struct gw_config {
 
 #define GW_CFG_PER_ENV_STATS  1             /* keep per-env event counters (tests); costs HBM traffic */
 #define GW_CFG_EXPLICIT_QUEUE 2             /* MAC queues as explicit rings of packet sizes (generic, slower);
-                                               default: exact run-length encoding of counter traffic */
+                                               default: exact suffix encoding of counter traffic, gw_queue.h */
 
 typedef struct gw_stats {                   /* totals since gw_create, over all envs */
     uint64_t steps;                         /* env-steps executed */
@@ -145,9 +145,9 @@ int gw_state_bytes(gw_env* env, uint64_t* bytes);       /* HBM held by this hand
 int gw_link_info(gw_env* env, int32_t from, int32_t to, double* attenuation_db, double* rx_power_mw);
 int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values_mw /* [16] */);
 
-/* Host-only self-test hook (no GPU needed): fuzzes the run-length MAC-queue encoding the kernels use
+/* Host-only self-test hook (no GPU needed): fuzzes the MAC-queue encoding the default kernel uses
  * against an explicit deque(maxlen=100).  Returns the number of mismatches (0 = identical). */
-int gw_selftest_rle(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);
+int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);
 
 /* Host-only: bit mask of the exact arithmetic fast paths gw_create enables for cfg after validating
  * them (1 slot remainder, 2 division by the data rate, 4 integer decode decision, 8 idempotent

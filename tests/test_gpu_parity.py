@@ -13,7 +13,7 @@ from util import action_stream, assert_state_equal, STATE_FIELDS, STAT_FIELDS
 pytestmark = pytest.mark.gpu
 
 
-QUEUE_MODES = [pytest.param(False, id="rle"), pytest.param(True, id="explicit")]
+QUEUE_MODES = [pytest.param(False, id="suffix"), pytest.param(True, id="explicit")]
 
 
 def _mk(num_envs, D, explicit=False, counter_bound=None, **kw):

@@ -505,7 +505,7 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = w[e];
         return GW_OK;
     }
-    if (!strcmp(field, "counter")) {
+    if (!strcmp(field, "counter") && st.counter) {
         NEED(N * D, uint32_t);
         std::vector<uint32_t> c(N);
         HIP_TRY(hipMemcpy(c.data(), st.counter, N * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -96,14 +96,12 @@ def main():
     N, D, K, W = args.envs, args.devices, args.steps, args.warmup
     env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, device=dev_t)
 
-    # outputs as three views of ONE 9*N-byte record buffer so that the end-of-step
-    # observation gather is a single RCCL all-gather without a packing kernel
-    rec = torch.empty(9 * N + 16, dtype=torch.uint8, device=dev_t)
-    obs = rec[0:4 * N].view(torch.int32)
-    rew = rec[4 * N:8 * N].view(torch.float32)
-    done = rec[8 * N:9 * N]
-    env._obs, env._rew, env._done = obs, rew, done
-    gathered = torch.empty((world, rec.numel()), dtype=torch.uint8, device=dev_t) if world > 1 else None
+    # outputs as three views of ONE packed record buffer so that the end-of-step observation
+    # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
+    from gymwipe_amd.sharding import ObservationGather, StepRecord
+    rec = StepRecord(N, dev_t)
+    env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
+    gather = ObservationGather(rec, world) if (world > 1 and not args.no_gather) else None
 
     g = torch.Generator(device=dev_t)
     g.manual_seed(1234 + rank)
@@ -115,8 +113,8 @@ def main():
         if i % RESET_EVERY == 0:
             env.reset()
         env.step(acts[i])
-        if gathered is not None and not args.no_gather:
-            dist.all_gather_into_tensor(gathered.view(-1), rec)
+        if gather is not None:
+            gather()
 
     for i in range(W):
         one(i)
@@ -178,7 +176,7 @@ def main():
                        "launches_per_step": 1, "stream_ms_per_step": stream_s / K * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "ct_step_kernel", "kernel_avg_us": kern_avg_s * 1e6,
+                         "kernel": "ct_step_sfx_kernel", "kernel_avg_us": kern_avg_s * 1e6,
                          "kernel_median_us": kern_ms[len(kern_ms) // 2] * 1e3,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "algorithmic_bytes_per_env_step": bytes_launch / N},

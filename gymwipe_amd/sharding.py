@@ -1,0 +1,67 @@
+"""
+Multi-GPU host logic: environments are independent (the reference runs one env per process),
+so a global batch is cut into contiguous per-rank shards with NO data-path collective.  The
+only exchange the north star asks for is the end-of-step observation gather: every rank's
+packed (obs, reward, done) record all-gathered once per step -- RCCL over xGMI on GPUs
+(backend "nccl"), gloo on CPU in the tests.
+
+The record is ONE contiguous byte buffer laid out [obs int32 x N | reward float32 x N |
+done uint8 x N | pad]; the step kernel writes straight into its three views, so the gather
+needs no packing kernel and is a single collective of 9*N (+pad) bytes per rank.
+"""
+import torch
+
+
+def shard_range(global_envs, world_size, rank):
+    """Contiguous block of env ids owned by `rank` (first `rem` ranks get one extra)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    base, rem = divmod(int(global_envs), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class StepRecord:
+    """Packed per-step output record of one rank: three typed views over one byte buffer."""
+    ALIGN = 16
+
+    def __init__(self, num_envs, device):
+        n = int(num_envs)
+        self.num_envs = n
+        self.nbytes = (9 * n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.obs = self.buf[0:4 * n].view(torch.int32)
+        self.reward = self.buf[4 * n:8 * n].view(torch.float32)
+        self.done = self.buf[8 * n:9 * n]
+
+    @staticmethod
+    def split(flat, num_envs):
+        """Views (obs, reward, done) into a flat record buffer (1-D uint8 tensor)."""
+        n = int(num_envs)
+        return (flat[0:4 * n].view(torch.int32), flat[4 * n:8 * n].view(torch.float32), flat[8 * n:9 * n])
+
+
+class ObservationGather:
+    """All-gather of equally sized StepRecords over the default process group."""
+
+    def __init__(self, record, world_size=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.world = world_size if world_size is not None else dist.get_world_size()
+        self.record = record
+        self.out = torch.empty(self.world * record.nbytes, dtype=torch.uint8, device=record.buf.device)
+
+    def __call__(self):
+        """Gather every rank's record; returns the [world, nbytes] byte tensor (valid after the
+        collective completes on the current stream)."""
+        self._dist.all_gather_into_tensor(self.out, self.record.buf)
+        return self.out.view(self.world, self.record.nbytes)
+
+    def unpack(self):
+        """(obs[W*N], reward[W*N], done[W*N]) of the whole job, rank-major (== global env order
+        for equal shards)."""
+        n = self.record.num_envs
+        rows = self.out.view(self.world, self.record.nbytes)
+        parts = [StepRecord.split(rows[r], n) for r in range(self.world)]
+        return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]),
+                torch.cat([p[2] for p in parts]))

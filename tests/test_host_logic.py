@@ -1,0 +1,155 @@
+"""
+CPU tier: host-side logic and the C-ABI surface.  No compute call is made without a GPU: the
+library must load, export every symbol include/gymwipe_amd.h declares, refuse loudly to create
+an env without a HIP device, and its host-only self-tests must pass.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    hdr = open(os.path.join(ROOT, "include", "gymwipe_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gw_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    from gymwipe_amd import _native
+    assert sorted(_native.EXPORTS) == declared, "python binding and header disagree"
+    for name in declared:
+        assert getattr(native_lib, name) is not None
+    assert native_lib.gw_abi_version() == 1
+
+
+def test_config_default_matches_reference_constants(native_lib):
+    """SURVEY.md Appendix E / the class constants of the reference."""
+    from gymwipe_amd import _native
+    cfg = _native.default_config(65536, 2)
+    assert (cfg.pos[0][0], cfg.pos[0][1]) == (0.0, 2.0)          # counter_traffic.py:125
+    assert (cfg.pos[1][0], cfg.pos[1][1]) == (0.0, -2.0)         # :126
+    assert (cfg.pos[2][0], cfg.pos[2][1]) == (0.0, 0.0)          # :133
+    assert list(cfg.mult)[:2] == [1, 3] and list(cfg.dest)[:2] == [1, 0]
+    assert cfg.slot == 1e-6 and cfg.frequency == 2.4e9 and cfg.bandwidth == 22e6
+    assert cfg.bit_rate == 133.33333e3 and cfg.code_rate == 0.75 and cfg.max_ber == 0.25
+    assert cfg.tx_power_dbm == 0.0 and cfg.counter_interval == 0.001 and cfg.counter_bound == 65536
+    assert (cfg.mac_header_bytes, cfg.net_header_bytes) == (13, 12)
+    assert (cfg.duration_factor, cfg.max_duration, cfg.payload_value) == (1000, 20, 2)
+    # D = 4: circle of radius 2 m, multiplicities 1,3,1,3; same layout as the oracle
+    from oracle.ct_oracle import default_config as ocfg
+    c4, o4 = _native.default_config(8, 4), ocfg(4)
+    for i in range(5):
+        assert (c4.pos[i][0], c4.pos[i][1]) == (o4.pos[i][0], o4.pos[i][1])
+    assert list(c4.mult)[:4] == list(o4.mult)[:4] == [1, 3, 1, 3]
+    assert native_lib.gw_config_default(C.byref(cfg), 8, 1) < 0   # D out of range
+    assert b"num_devices" in native_lib.gw_last_error()
+
+
+@pytest.mark.parametrize("mult,bound", [(1, 65536), (3, 65536), (3, 40), (2, 7), (15, 1), (5, 300)])
+def test_queue_encoding_fuzz_against_explicit_deque(native_lib, mult, bound):
+    """gw_queue.h (the code the kernel runs) vs deque(maxlen=100): ticks, resets, pops."""
+    for seed in range(3):
+        assert native_lib.gw_selftest_queue(seed, 30000, mult, bound) == 0
+
+
+def test_fast_paths_validate_for_default_configs(native_lib):
+    from gymwipe_amd import _native
+    for D, want_states in ((2, 3), (4, 4), (16, 6), (32, 8)):
+        cfg = _native.default_config(1024, D)
+        mx = C.c_int32()
+        mask = native_lib.gw_selftest_fastmath(C.byref(cfg), C.byref(mx))
+        assert mask == 15, "D=%d: fast paths %d" % (D, mask)
+        assert mx.value == want_states
+    cfg = _native.default_config(16, 4)
+    cfg.code_rate, cfg.max_ber = 0.5, 0.11                # integer decode shortcut must switch itself off
+    assert native_lib.gw_selftest_fastmath(C.byref(cfg), None) & 4 == 0
+    cfg = _native.default_config(16, 4)
+    cfg.mult[1] = 99                                      # suffix encoding supports mult <= 15
+    assert native_lib.gw_selftest_fastmath(C.byref(cfg), None) < 0
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback_without_a_gpu(native_lib):
+    """The product path must fail loudly when there is no HIP device -- never fall back."""
+    from gymwipe_amd import _native
+    cfg = _native.default_config(16, 2)
+    h = C.c_void_p()
+    rc = native_lib.gw_create(C.byref(cfg), C.byref(h))
+    assert rc == _native.ENODEVICE and not h
+    assert b"no CPU fallback" in native_lib.gw_last_error()
+    import gymwipe_amd
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gymwipe_amd.VecCounterTrafficEnv(16)
+    with pytest.raises(RuntimeError):
+        gymwipe_amd.make("CounterTraffic-v0")
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under gymwipe_amd/ or include/ may reference it."""
+    bad = []
+    pat = re.compile(r"(from\s+oracle|import\s+oracle|ct_oracle|des_model|libct_oracle|oracle[/\\.]\w)")
+    for base in ("gymwipe_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h")):
+                    for line in open(os.path.join(dirpath, f), errors="replace"):
+                        if pat.search(line):
+                            bad.append((f, line.strip()))
+    assert not bad, bad
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(ROOT, "gymwipe_amd", "lib", "libgymwipe_amd.so")],
+                         capture_output=True, text=True).stdout
+    assert "ct_oracle" not in out
+
+
+def test_spaces_and_registry_surface():
+    import gymwipe_amd
+    from gymwipe_amd import spaces
+    act = spaces.Dict({"device": spaces.Discrete(2), "duration": spaces.Discrete(20)})   # envs/core.py:39-42
+    assert act.contains({"device": 1, "duration": 19})
+    assert not act.contains({"device": 2, "duration": 0})
+    assert not act.contains({"device": 0, "duration": 20})
+    assert not act.contains({"device": 0})
+    assert not act.contains({"device": 0.0, "duration": 1})
+    assert act.contains({"device": np.int64(1), "duration": np.int32(3)})
+    act.seed(1)
+    for _ in range(50):
+        assert act.contains(act.sample())
+    assert spaces.Discrete(131072).n == 2 * 65536                                       # counter_traffic.py:120
+    assert set(gymwipe_amd.registry) >= {"CounterTraffic-v0", "VecCounterTraffic-v0"}
+    with pytest.raises(KeyError):
+        gymwipe_amd.make("InvertedPendulum-v0")
+    E = gymwipe_amd.VecCounterTrafficEnv
+    assert (E.MAX_ASSIGN_DURATION, E.ASSIGNMENT_DURATION_FACTOR) == (20, 1000)          # envs/core.py:25,27
+    assert (E.COUNTER_INTERVAL, E.COUNTER_BYTE_LENGTH, E.COUNTER_BOUND) == (0.001, 2, 65536)
+    for name in ("onPacketReceived", "onFrequencyBandAssignment", "getReward", "getObservation",
+                 "getDone", "getInfo", "getFeedback", "reset"):                        # envs/core.py:59-159
+        assert hasattr(gymwipe_amd.Interpreter, name)
+
+
+def test_shard_range_partitions_the_batch():
+    from gymwipe_amd.sharding import shard_range
+    for total, world in ((524288, 8), (65536, 1), (10, 4), (7, 8)):
+        spans = [shard_range(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        for a, b in zip(spans, spans[1:]):
+            assert a[1] == b[0]
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def test_bench_algorithmic_byte_model():
+    """B(D) = 17 + 2*(12 + 20*D) + 4*(k_app + k_pop)."""
+    import bench
+    assert bench.algorithmic_bytes(4, 1, 0, 0) == 17 + 2 * (12 + 80)
+    assert bench.algorithmic_bytes(2, 10, 440, 10) == 10 * (17 + 2 * 52) + 4 * 450
+    assert bench.HBM_PEAK == 8.0e12

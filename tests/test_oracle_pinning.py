@@ -1,0 +1,172 @@
+"""
+CPU tier: the oracle against the known answers the reference's own tests hold
+(tests/golden/reference_known_answers.json), and the two oracle layers against each other.
+
+Chain of evidence (DESIGN.md "Oracle"):
+  reference test assertions  ->  oracle/des_model.py (event-driven restatement, small cases)
+                             ->  oracle/ct_oracle.c  (flattened C restatement, bit-for-bit equal)
+                             ->  HIP path (tests/test_gpu_parity.py, -m gpu)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import des_model as dm
+from oracle.ct_oracle import CtOracle, default_config, FLAG_CARRY, FLAG_REFEXC
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+# ---- layer 1 (event-driven restatement) against the reference's own test assertions ------------
+def test_des_counter_traffic_known_answer():
+    got, _ = dm.scenario_counter_traffic()
+    want = GOLD["counter_traffic_env"]["steps"]
+    assert [(o, r) for o, r in got] == [(s["obs_minus_center"], float(s["reward"])) for s in want]
+
+
+def test_des_simple_mac_known_answer():
+    w = GOLD["simple_mac"]["delivered_after_rounds"]
+    assert dm.scenario_simple_mac() == [w["round1_device2"], w["round2_device1"], w["round3_device2"],
+                                        w["round4_device1"], w["final_device1"], w["final_device2"]]
+
+
+def test_des_simple_phy_known_answer():
+    out = dm.scenario_simple_phy()
+    a = GOLD["simple_phy"]["asserts"]
+    assert out["idle_before"] == a["active_before"]
+    assert out["active_during"] == a["active_during"] and out["tx_fields_ok"]
+    assert out["power_dropped"] is a["power_drops_when_moving_away"]
+    assert out["active_after"] == a["active_after"]
+    assert out["delivered_last_is_packet"] is a["packet_delivered"]
+
+
+def test_des_notifier_admission_known_answer():
+    got = dm.scenario_notifier_admission()
+    want = GOLD["notifier_admission"]["instances_and_last_value"]
+    t4, t15, t16, t41 = got
+    assert [list(x) for x in t4] == want["t4"]
+    assert [x[0] for x in t15] == [x[0] for x in want["t15"]] and list(t15[2]) == want["t15"][2]
+    assert list(t16[1]) == want["t16"][1]
+    assert [list(x) for x in t41] == want["t41"]
+
+
+# ---- layer 2 (C restatement) against the same known answer -----------------------------------------
+def test_c_oracle_counter_traffic_known_answer():
+    orc = CtOracle(1, 2)
+    center = GOLD["counter_traffic_env"]["observation_center"]
+    for s in GOLD["counter_traffic_env"]["steps"]:
+        o, r, d = orc.step([s["action"]["device"]], [s["action"]["duration"]])
+        assert int(o[0]) - center == s["obs_minus_center"] and float(r[0]) == s["reward"] and not d[0]
+
+
+# ---- layer 2 == layer 1, bit for bit --------------------------------------------------------------
+def _compare(D, steps, seed, reset_every=None, fresh_reset=True, positions=None, mult=None, bound=None):
+    rng = np.random.default_rng(seed)
+    pos = positions or dm.circle_layout(D)
+    mult = mult or dm.default_multiplicity(D)
+    py = dm.CounterTrafficModel(D, positions=pos, mult=mult)
+    cfg = default_config(D, positions=pos, mult=mult)
+    co = CtOracle(1, D, config=cfg)
+    if fresh_reset:
+        assert py.reset() == co.reset()[0]
+    for k in range(steps):
+        if reset_every and k and k % reset_every == 0:
+            assert py.reset() == co.reset()[0]
+        d, du = int(rng.integers(0, D)), int(rng.integers(0, 20))
+        o, r, dn, _ = py.step(d, du)
+        oc, rc, dc = co.step([d], [du])
+        s = py.snapshot()
+        assert (o, r, dn) == (int(oc[0]), float(rc[0]), bool(dc[0])), "outputs differ at step %d" % k
+        assert s["now"] == co.get("now")[0], "simulated time differs at step %d" % k
+        assert s["counters"] == co.get("counter")[0].tolist()
+        assert s["qlen"] == co.get("qlen")[0].tolist()
+        assert s["received"] == co.get("received")[0].tolist()
+        assert s["rx_power"] == co.get("rx_power")[0].tolist(), "rx power residue differs at step %d" % k
+        assert s["n_tx"] == int(co.get("n_tx")[0])
+        q = co.get("queue")[0]
+        for i in range(D):
+            assert s["queues"][i] == q[i][:s["qlen"][i]].tolist(), "queue %d differs at step %d" % (i, k)
+    assert int(co.get("flags")[0]) & (FLAG_CARRY | FLAG_REFEXC) == 0
+
+
+@pytest.mark.parametrize("D,steps,seed,reset_every,fresh", [
+    (2, 40, 1, None, False),     # the reference test's situation: no reset, counters start at 1
+    (2, 200, 2, None, True),     # long run into queue overflow
+    (2, 150, 3, 64, True),
+    (4, 120, 4, 32, True),
+    (16, 60, 5, 16, True),
+])
+def test_c_oracle_equals_event_driven_restatement(D, steps, seed, reset_every, fresh):
+    _compare(D, steps, seed, reset_every, fresh)
+
+
+def test_c_oracle_equals_event_driven_restatement_other_geometry():
+    # a sender far enough (11 m) that the RRM cannot decode its payload: exercises failed receptions
+    pos = [(0.0, 2.0), (0.0, -11.0), (3.0, 0.0)]
+    _compare(3, 80, 6, 20, True, positions=pos, mult=[2, 1, 3])
+
+
+# ---- secondary cross-check against SURVEY.md's probe values (NOT reference output) ----------------
+def test_secondary_survey_probe_values():
+    p = GOLD["survey_probe_secondary"]
+    orc = CtOracle(1, 2)
+    assert orc.thermal_mw() == p["thermal_noise_mw"]
+    assert orc.data_rate() == p["data_rate"]
+    assert orc.attenuation(0, 2) == p["attenuation_2m_db"]
+    assert orc.attenuation(0, 1) == p["attenuation_4m_db"]
+    assert orc.rx_power_mw(2, 0) == p["rx_power_2m_mw"]
+    assert orc.ber(orc.rx_power_mw(2, 0), orc.thermal_mw()) == pytest.approx(p["ber_2m"], rel=1e-9)
+    assert orc.ber(orc.rx_power_mw(1, 0), orc.thermal_mw()) == pytest.approx(p["ber_4m"], rel=1e-9)
+    assert dm.BpskMcs().max_correctable_ber() == p["max_ber_3_4"]
+    tr = p["trace"]
+    orc.step([0], [3])
+    assert orc.get("now")[0] == tr["after_step1"]["now"]
+    assert orc.get("counter")[0].tolist() == tr["after_step1"]["counters"]
+    assert orc.get("qlen")[0].tolist() == tr["after_step1"]["qlen"]
+    orc.step([1], [12])
+    assert orc.get("now")[0] == tr["after_step2"]["now"]
+    assert orc.get("counter")[0].tolist() == tr["after_step2"]["counters"]
+    assert orc.get("qlen")[0].tolist() == tr["after_step2"]["qlen"]
+    for key in ("step3", "step4"):
+        s = tr[key]
+        o, r, _ = orc.step([s["action"]["device"]], [s["action"]["duration"]])
+        assert int(o[0]) - 65536 == s["obs_minus_center"] and float(r[0]) == s["reward"]
+        assert orc.get("now")[0] == s["now"]
+    _, env = dm.scenario_counter_traffic()
+    got = [[t.start, t.packet.byte_size, t.stop] for t in env.world.band.log]
+    assert got == tr["transmissions_first_two_steps"]
+
+
+# ---- properties of the oracle itself ---------------------------------------------------------------
+def test_oracle_is_deterministic_and_invariants_hold():
+    D, N, K = 4, 64, 80
+    rng = np.random.default_rng(9)
+    dev = rng.integers(0, D, (K, N), dtype=np.int32)
+    dur = rng.integers(0, 20, (K, N), dtype=np.int32)
+    a, b = CtOracle(N, D), CtOracle(N, D, nthreads=4)
+    a.reset(); b.reset()
+    t_prev = a.get("now").copy()
+    for k in range(K):
+        ra, rb = a.step(dev[k], dur[k]), b.step(dev[k], dur[k])
+        for x, y in zip(ra, rb):
+            assert (x == y).all()
+        t = a.get("now")
+        dt = t - t_prev                                    # 1.12 ms .. 20.45 ms per step
+        assert (dt > 1.1e-3).all() and (dt < 20.5e-3).all()
+        t_prev = t.copy()
+        assert set(np.unique(ra[0]).tolist()) <= {65534, 65536, 65538}
+        assert set(np.unique(ra[1]).tolist()) <= {-2.0, 0.0, 2.0}
+        assert not ra[2].any()
+    assert (a.get("qlen") <= 100).all() and (a.get("counter") <= 65536).all()
+    for f in ("now", "rx_power", "queue"):
+        assert (a.get(f).view(np.uint8) == b.get(f).view(np.uint8)).all()
+
+
+def test_oracle_rejects_invalid_actions():
+    orc = CtOracle(2, 2)
+    with pytest.raises(AssertionError):
+        orc.step([0, 2], [1, 1])                           # counter_traffic.py:147
+    with pytest.raises(AssertionError):
+        orc.step([0, 1], [20, 1])

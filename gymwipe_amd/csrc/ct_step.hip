@@ -253,16 +253,7 @@ __global__ void ct_init_kernel(GwState st)
     const int D = st.cst->D, R = st.cst->R;
     st.now[e] = 0.0;
     st.wake[e] = 0.0;
-    if (st.counter) st.counter[e] = 1u;
-    if (st.tau) {                                   // suffix encoding: first breakpoint (tick 0, counter 1)
-        GwBp b; b.t0 = 0u; b.c0 = 1u;
-        st.tau[e] = 0u;
-        st.nbp[e] = 1u;
-        st.bpc[e] = b;
-        st.bpp[e] = b;
-        st.bph[(int64_t)e << 7] = b;
-        for (int i = 0; i < D; ++i) st.qlen[(int64_t)i * N + e] = 0;
-    }
+    st.counter[e] = 1u;
     st.rvmask[e] = 0u;
     st.last_abs[e] = 0;
     st.done[e] = 0;

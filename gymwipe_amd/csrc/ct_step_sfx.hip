@@ -1,10 +1,16 @@
-// ct_step_sfx.hip -- the default step kernel.  MAC queues in the "suffix" encoding of gw_queue.h:
-// one length byte per sender, a tick counter and the reset breakpoints per env.  A counter tick is
-// `len = min(len + mult, 100)`, a pop is `len -= 1`, the head packet's size is arithmetic on the tick
-// index -- no queue memory is touched by the step at all, so the kernel issues every load up front,
-// walks the step's event horizon in registers, and stores once.
+// ct_step_sfx.hip -- the default step kernel (+ its init / reset / readout kernels).
 //
-// Step walk, reference file:line as in ct_common.hip.h / ct_step.hip:
+// MAC queues in the "suffix" encoding of gw_queue.h: one length byte per sender, a tick counter and
+// the reset breakpoints per env.  A counter tick is `len = min(len + mult, 100)`, a pop is `len -= 1`,
+// the head packet's size is arithmetic on the tick index.  The step therefore touches no queue memory:
+// it loads four 16-byte records per env, walks the event horizon of the step in registers, and stores
+// the records back.  Per-env HBM layout (all offsets 32-bit):
+//     tw[e] = {now, next tick}                      2 x f64
+//     tk[e] = {tau, nbp, newest breakpoint}         4 x u32
+//     ip[e] = {2nd newest breakpoint, rvmask, last_abs | done<<31}
+//     qb[e] = bytes: len[0..D), rx-power state[0..D], pad to 16
+//
+// Step walk, reference file:line:
 //   A.1  t_s = t_a + (slot - t_a % slot)                                   simtools.py:44-53
 //   A.2  announcement heard by the addressed sender (header, payload)      simple_stack.py:214-286,536-558
 //   A.3  window: pop + transmit while (stop - now) > bits/dataRate         simple_stack.py:397-434
@@ -18,6 +24,41 @@ using namespace gwk;
 
 namespace {
 
+template <class T>
+__device__ __forceinline__ T ld(const void* base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_(void* base, uint32_t byte_off, const T& v)
+{
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// byte `idx` (0..15) of a 16-byte record held in registers, idx not known at compile time
+__device__ __forceinline__ uint32_t byte_of(const uint4& w, uint32_t idx)
+{
+    const uint32_t lo = (idx & 4u) ? w.y : w.x;
+    const uint32_t hi = (idx & 4u) ? w.w : w.z;
+    const uint32_t v = (idx & 8u) ? hi : lo;
+    return (v >> ((idx & 3u) * 8u)) & 0xffu;
+}
+__device__ __forceinline__ uint32_t word_of(const uint4& w, int i)          // i compile-time after unrolling
+{
+    return i == 0 ? w.x : (i == 1 ? w.y : (i == 2 ? w.z : w.w));
+}
+
+// Decode outcome of one reception: certain by class, or the exact arithmetic (ct_common.hip.h)
+__device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls_valid, double ber, const TxTimes& x,
+                                       double br, double hdr_bits, double pay_bits, uint32_t& fl)
+{
+    if (!(x.t_e >= x.stop)) fl |= GW_FLAG_REFEXC;        // `not t.completed` -> KeyError in the reference
+    if (cls_valid && cls != GW_CLS_COMPUTE) return cls == GW_CLS_OK;
+    uint32_t dummy = 0;
+    return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
+}
+
+// NW = 16-byte words of the qb record held in registers (1 for D <= 7); NW == 0: bytes stay in memory
 template <int DT, bool PER_ENV_STATS>
 __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
                                                          const int32_t* __restrict__ device,
@@ -26,11 +67,13 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
                                                          float* __restrict__ reward,
                                                          uint8_t* __restrict__ done)
 {
-    const int64_t N = st.N;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr bool PACKED = (DT > 0 && DT <= 7);         // the whole byte record fits one uint4
+    const uint32_t N = (uint32_t)st.N;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const GwDevConst& c = *st.cst;
     const int D = DT > 0 ? DT : c.D;
     const int R = D + 1, S = c.S, RRM = D;
+    const uint32_t RB = PACKED ? 16u : (uint32_t)st.RB;
 
     Tally k = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
@@ -38,9 +81,11 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
     if (e < N) {
         const int d = device[e];
         const int du = duration[e];
-        uint32_t rvm = st.rvmask[e];
-        int32_t last_abs = st.last_abs[e];
-        uint8_t dn = st.done[e];
+        const uint32_t o16 = e << 4;
+        const uint4 ip = ld<uint4>(st.ip, o16);
+        uint32_t rvm = ip.z;
+        int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
+        uint32_t dn = ip.w >> 31;
         const int pv = c.payload_value;
         uint32_t fl = 0;
 
@@ -51,7 +96,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
             obs[e] = latest + c.counter_bound;
             reward[e] = 0.0f;
-            done[e] = dn;
+            done[e] = (uint8_t)dn;
         } else {
             k_steps = 1;
             const StepMath m(c);
@@ -64,29 +109,43 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             const bool idem = c.idem_states != 0;
 
             // ---- every load of the step is issued up here, before anything is stored ------------
-            const double t_a = st.now[e];
-            double wake = st.wake[e];
-            const uint32_t tau0 = st.tau[e];
-            const uint32_t nbp = st.nbp[e];
-            const GwBp bpc = st.bpc[e];
-            const GwBp bpp = st.bpp[e];
-            const GwBp* hist = st.bph + ((int64_t)e << 7);
-            uint32_t len_d = st.qlen[(int64_t)d * N + e];
-            uint8_t li[DT > 0 ? DT : 1], sj[DT > 0 ? DT : 1];
-            if (DT > 0) {
-#pragma unroll
-                for (int i = 0; i < DT; ++i) { li[i] = st.qlen[(int64_t)i * N + e]; sj[i] = st.rxs[(int64_t)i * N + e]; }
+            const double2 tw = ld<double2>(st.tw, o16);
+            const uint4 tk = ld<uint4>(st.tk, o16);
+            const uint32_t oq = e * RB;
+            uint4 qw = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t len_d, s_d_old, s_r_old;
+            if (PACKED) {
+                qw = ld<uint4>(st.qb, oq);
+                len_d = byte_of(qw, (uint32_t)d);
+                s_d_old = byte_of(qw, (uint32_t)(DT + d));
+                s_r_old = byte_of(qw, (uint32_t)(2 * DT));
+            } else {
+                len_d = st.qb[oq + (uint32_t)d];
+                s_d_old = st.qb[oq + (uint32_t)(D + d)];
+                s_r_old = st.qb[oq + (uint32_t)(2 * D)];
             }
-            const uint8_t s_d_old = st.rxs[(int64_t)d * N + e];
-            const uint8_t s_r_old = st.rxs[(int64_t)RRM * N + e];
+            const double t_a = tw.x;
+            double wake = tw.y;
+            const uint32_t tau0 = tk.x, nbp = tk.y;
+            GwBp bpc, bpp;
+            bpc.t0 = tk.z; bpc.c0 = tk.w;
+            bpp.t0 = ip.x; bpp.c0 = ip.y;
+            const GwBp* hist = st.bph + ((size_t)e << 7);
             // what the addressed sender / the RRM become after hearing the RRM / sender d once
-            const uint8_t s_d = st.trans[((int64_t)d * R + RRM) * S + s_d_old];
-            const double ber_a = st.ber[((int64_t)d * R + RRM) * S + s_d];
-            uint8_t s_r = s_r_old;
-            const uint8_t s_r1 = st.trans[((int64_t)RRM * R + d) * S + s_r_old];
-            const double ber_x1 = st.ber[((int64_t)RRM * R + d) * S + s_r1];
+            const uint32_t ia = (uint32_t)((d * R + RRM) * S) + s_d_old;
+            const uint32_t s_d = st.trans[ia];
+            const uint32_t ja = (uint32_t)((d * R + RRM) * S) + s_d;
+            const double ber_a = st.ber[ja];
+            const uint32_t cls_a = st.cls[ja];
+            const uint32_t ix = (uint32_t)((RRM * R + d) * S) + s_r_old;
+            const uint32_t s_r1 = st.trans[ix];
+            const uint32_t jx = (uint32_t)((RRM * R + d) * S) + s_r1;
+            const double ber_x1 = st.ber[jx];
+            const uint32_t cls_x1 = st.cls[jx];
+            uint32_t s_r = s_r_old;
             const uint32_t mult_d = (uint32_t)c.mult[d];
             const uint32_t inv16_d = c.inv16[d];
+            const bool cls_valid = t_a < c.cls_limit;
 
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
@@ -94,7 +153,8 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             const int L = ndigits(slots);
             const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(L * 8)));
             k.tx++;
-            const bool granted = receive(m, ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, fl);
+            const bool granted = decode(m, cls_a, cls_valid, ber_a, an, br, hdr_bits,
+                                        (double)(L * 8) * c.coded_factor, fl);
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
@@ -103,13 +163,21 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             int n_data = 0;
             Tally kd = {0, 0, 0, 0, 0};                                   // appends/drops of sender d only
 
-            // all counter ticks with wake < t (or <= t): counted in f64, applied to d's queue length
+            // all counter ticks with wake < t (or <= t): counted in f64 four at a time (the running
+            // sum w += dt is the reference's arithmetic), applied to d's queue length in one go
             auto ticks_to = [&](double t, bool inclusive) {
                 uint32_t kk = 0;
-                while (wake < t || (inclusive && wake == t)) {
-                    if (wake == t) fl |= GW_FLAG_TIE;
-                    wake = wake + interval;                               // running sum, not k*dt
-                    kk++;
+                for (;;) {
+                    const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
+                    const bool b0 = inclusive ? (wake <= t) : (wake < t);
+                    const bool b1 = inclusive ? (w1 <= t) : (w1 < t);
+                    const bool b2 = inclusive ? (w2 <= t) : (w2 < t);
+                    const bool b3 = inclusive ? (w3 <= t) : (w3 < t);
+                    if (inclusive && (wake == t || w1 == t || w2 == t || w3 == t)) fl |= GW_FLAG_TIE;
+                    const uint32_t n = (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;   // monotone
+                    wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
+                    kk += n;
+                    if (!b3) break;
                 }
                 tau += kk;
                 len_d = gw_len_after_ticks(len_d, kk, mult_d, kd);
@@ -141,17 +209,20 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
                     k.tx++;
                     n_data++;
                     double ber_x = ber_x1;
+                    uint32_t cls_x = cls_x1;
                     if (idem) {
                         s_r = s_r1;
                     } else {
-                        s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
-                        ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
+                        s_r = st.trans[(uint32_t)((RRM * R + d) * S) + s_r];
+                        ber_x = st.ber[(uint32_t)((RRM * R + d) * S) + s_r];
+                        cls_x = st.cls[(uint32_t)((RRM * R + d) * S) + s_r];
                     }
-                    const bool ok = receive(m, ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl);
+                    const bool ok = decode(m, cls_x, cls_valid, ber_x, x, br, hdr_bits,
+                                           (double)(pay * 8) * c.coded_factor, fl);
                     if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
                         k.deliv++;
                         rvm |= (1u << d);
-                        if (pv == c.counter_bound) dn = 1;
+                        if (pv == c.counter_bound) dn = 1u;
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
                     ticks_to(x.t_e, true);                                // ticks are older events than the MAC's resume
@@ -166,45 +237,50 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             k.app += kd.app;
             k.drop += kd.drop;
 
-            // ---- rx-power state of the radios that only listened (simple_stack.py:130-157) -----
-            // (table lookups are loads too: they come before the first store)
-            auto heard = [&](int j, uint8_t s0) {
-                uint8_t s = st.trans[((int64_t)j * R + RRM) * S + s0];
+            // ---- every other sender saw the same n_ticks ticks; every other radio heard the
+            //      announcement and, if any, d's data (simple_stack.py:130-157) ------------------
+            auto heard = [&](int j, uint32_t s0) {
+                uint32_t s = st.trans[(uint32_t)((j * R + RRM) * S) + s0];
                 for (int n = 0; n < n_data; ++n) {
-                    const uint8_t s2 = st.trans[((int64_t)j * R + d) * S + s];
+                    const uint32_t s2 = st.trans[(uint32_t)((j * R + d) * S) + s];
                     if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
                     s = s2;
                 }
                 return s;
             };
-            uint8_t sn[DT > 0 ? DT : 1];
-            if (DT > 0) {
+            if (PACKED) {
+                uint32_t nb[16];
 #pragma unroll
-                for (int j = 0; j < DT; ++j) sn[j] = heard(j, sj[j]);
-            }
-
-            // ---- stores ------------------------------------------------------------------------
-            st.qlen[(int64_t)d * N + e] = (uint8_t)len_d;
-            // every other sender saw the same n_ticks ticks
-            if (DT > 0) {
+                for (int b = 0; b < 16; ++b) nb[b] = (word_of(qw, b >> 2) >> ((b & 3) * 8)) & 0xffu;
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    if (i == d) continue;
-                    st.qlen[(int64_t)i * N + e] = (uint8_t)gw_len_after_ticks(li[i], n_ticks, (uint32_t)c.mult[i], k);
-                    if (sn[i] != sj[i]) st.rxs[(int64_t)i * N + e] = sn[i];
+                    Tally ki = {0, 0, 0, 0, 0};
+                    const uint32_t li = gw_len_after_ticks(nb[i], n_ticks, (uint32_t)c.mult[i], ki);
+                    const uint32_t si = heard(i, nb[DT + i]);             // table lookups: loads, before any store
+                    if (i != d) { k.app += ki.app; k.drop += ki.drop; }   // d's own ticks were counted in the window
+                    nb[i] = (i == d) ? len_d : li;
+                    nb[DT + i] = (i == d) ? s_d : si;
                 }
+                nb[2 * DT] = s_r;
+                uint4 o;
+                o.x = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24);
+                o.y = nb[4] | (nb[5] << 8) | (nb[6] << 16) | (nb[7] << 24);
+                o.z = nb[8] | (nb[9] << 8) | (nb[10] << 16) | (nb[11] << 24);
+                o.w = nb[12] | (nb[13] << 8) | (nb[14] << 16) | (nb[15] << 24);
+                st_(st.qb, oq, o);
             } else {
                 for (int i = 0; i < D; ++i) {
                     if (i == d) continue;
-                    const uint32_t l0 = st.qlen[(int64_t)i * N + e];
-                    const uint8_t s0 = st.rxs[(int64_t)i * N + e];
-                    const uint8_t s1 = heard(i, s0);
-                    st.qlen[(int64_t)i * N + e] = (uint8_t)gw_len_after_ticks(l0, n_ticks, (uint32_t)c.mult[i], k);
-                    if (s1 != s0) st.rxs[(int64_t)i * N + e] = s1;
+                    const uint32_t l0 = st.qb[oq + (uint32_t)i];
+                    const uint32_t s0 = st.qb[oq + (uint32_t)(D + i)];
+                    const uint32_t s1 = heard(i, s0);
+                    st.qb[oq + (uint32_t)i] = (uint8_t)gw_len_after_ticks(l0, n_ticks, (uint32_t)c.mult[i], k);
+                    if (s1 != s0) st.qb[oq + (uint32_t)(D + i)] = (uint8_t)s1;
                 }
+                st.qb[oq + (uint32_t)d] = (uint8_t)len_d;
+                if (s_d != s_d_old) st.qb[oq + (uint32_t)(D + d)] = (uint8_t)s_d;
+                if (s_r != s_r_old) st.qb[oq + (uint32_t)(2 * D)] = (uint8_t)s_r;
             }
-            if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
-            if (s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
 
             // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
@@ -214,20 +290,17 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             r = r > 10 ? 10 : (r < -10 ? -10 : r);
             obs[e] = latest + c.counter_bound;
             reward[e] = (float)r;
-            done[e] = dn;
+            done[e] = (uint8_t)dn;
 
-            st.now[e] = t_end;
-            st.wake[e] = wake;
-            st.tau[e] = tau;
-            st.rvmask[e] = rvm;
-            st.last_abs[e] = last_abs;
-            st.done[e] = dn;
+            st_(st.tw, o16, make_double2(t_end, wake));
+            st_(st.tk, o16, tau);                                         // only the tick counter changes
+            st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
             if (PER_ENV_STATS) {
-                st.pe_stats[0 * N + e] += k.tx;
-                st.pe_stats[1 * N + e] += k.deliv;
-                st.pe_stats[2 * N + e] += k.app;
-                st.pe_stats[3 * N + e] += k.pop;
-                st.pe_stats[4 * N + e] += k.drop;
+                st.pe_stats[0 * (size_t)N + e] += k.tx;
+                st.pe_stats[1 * (size_t)N + e] += k.deliv;
+                st.pe_stats[2 * (size_t)N + e] += k.app;
+                st.pe_stats[3 * (size_t)N + e] += k.pop;
+                st.pe_stats[4 * (size_t)N + e] += k.drop;
             }
         }
         if (fl) st.flags[e] |= fl;                                         // rare: sticky flags
@@ -236,35 +309,62 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
     publish_totals(st.totals, k, k_steps, k_bad, fl_new);
 }
 
+// fresh env: counters 1 (counter_traffic.py:48) == breakpoint (tick 0, value 1); first tick at t = 0;
+// queues empty; every radio at thermal noise (state 0)
+__global__ void ct_init_sfx_kernel(GwState st)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint32_t)st.N) return;
+    const uint32_t o16 = e << 4;
+    st_(st.tw, o16, make_double2(0.0, 0.0));
+    st_(st.tk, o16, make_uint4(0u, 1u, 0u, 1u));
+    st_(st.ip, o16, make_uint4(0u, 1u, 0u, 0u));
+    for (int b = 0; b < st.RB; ++b) st.qb[e * (uint32_t)st.RB + b] = 0;
+    GwBp b0; b0.t0 = 0u; b0.c0 = 1u;
+    st.bph[(size_t)e << 7] = b0;
+    st.flags[e] = 0u;
+    if (st.pe_stats) for (int s = 0; s < 5; ++s) st.pe_stats[(size_t)s * st.N + e] = 0ull;
+}
+
 // counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound.
 // In the suffix encoding "counters <- 0" is a new breakpoint (tau, 0).
 __global__ void ct_reset_sfx_kernel(GwState st, const uint8_t* __restrict__ mask, int32_t* __restrict__ obs)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= st.N) return;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint32_t)st.N) return;
+    const uint32_t o16 = e << 4;
+    uint32_t rvm;
     if (!mask || mask[e]) {
-        const uint32_t tau = st.tau[e];
-        const uint32_t n = st.nbp[e];
-        GwBp cur = st.bpc[e];
-        if (cur.t0 == tau) {                       // no tick since the last breakpoint: overwrite it
+        uint4 tk = ld<uint4>(st.tk, o16);
+        GwBp cur; cur.t0 = tk.z; cur.c0 = tk.w;
+        if (cur.t0 == tk.x) {                      // no tick since the newest breakpoint: overwrite it
             cur.c0 = 0u;
-            st.bpc[e] = cur;
-            st.bph[((int64_t)e << 7) + ((n - 1u) & GW_RING_MASK)] = cur;
+            st.bph[((size_t)e << 7) + ((tk.y - 1u) & GW_RING_MASK)] = cur;
+            tk.w = 0u;
+            st_(st.ip, o16 + 8u, make_uint2(0u, 0u));
         } else {
-            st.bpp[e] = cur;
-            cur.t0 = tau; cur.c0 = 0u;
-            st.bpc[e] = cur;
-            st.bph[((int64_t)e << 7) + (n & GW_RING_MASK)] = cur;
-            st.nbp[e] = n + 1u;
+            st_(st.ip, o16, make_uint4(cur.t0, cur.c0, 0u, 0u));   // old newest becomes second newest
+            cur.t0 = tk.x; cur.c0 = 0u;
+            st.bph[((size_t)e << 7) + (tk.y & GW_RING_MASK)] = cur;
+            tk.y += 1u; tk.z = cur.t0; tk.w = 0u;
         }
-        st.rvmask[e] = 0u;
-        st.last_abs[e] = 0;
-        st.done[e] = 0;
+        st_(st.tk, o16, tk);
+        rvm = 0u;
+    } else {
+        rvm = ld<uint4>(st.ip, o16).z;
     }
-    if (obs) {
-        const uint32_t rvm = st.rvmask[e];
-        obs[e] = st.cst->payload_value * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u)) + st.cst->counter_bound;
-    }
+    if (obs) obs[e] = st.cst->payload_value * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u)) + st.cst->counter_bound;
+}
+
+__global__ void ct_received_sfx_kernel(GwState st, int32_t* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = st.D;
+    if (idx >= st.N * D) return;
+    const uint32_t e = (uint32_t)(idx / D);
+    const int i = (int)(idx - (int64_t)e * D);
+    const uint32_t rvm = ld<uint4>(st.ip, e << 4).z;
+    out[idx] = ((rvm >> i) & 1u) ? st.cst->payload_value : 0;
 }
 
 template <int DT>
@@ -282,6 +382,8 @@ int launch(const GwState& st, const int32_t* device, const int32_t* duration,
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
+inline int ok_or_ehip() { return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP; }
+
 } // namespace
 
 int gw_launch_step_sfx(const GwState& st, const int32_t* device, const int32_t* duration,
@@ -289,16 +391,31 @@ int gw_launch_step_sfx(const GwState& st, const int32_t* device, const int32_t* 
 {
     switch (st.D) {
     case 2:  return launch<2>(st, device, duration, obs, reward, done, stream);
+    case 3:  return launch<3>(st, device, duration, obs, reward, done, stream);
     case 4:  return launch<4>(st, device, duration, obs, reward, done, stream);
-    case 8:  return launch<8>(st, device, duration, obs, reward, done, stream);
-    case 16: return launch<16>(st, device, duration, obs, reward, done, stream);
+    case 6:  return launch<6>(st, device, duration, obs, reward, done, stream);
     default: return launch<0>(st, device, duration, obs, reward, done, stream);
     }
+}
+
+int gw_launch_init_sfx(const GwState& st, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + 255) / 256);
+    hipLaunchKernelGGL(ct_init_sfx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st);
+    return ok_or_ehip();
 }
 
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream)
 {
     const unsigned grid = (unsigned)((st.N + 255) / 256);
     hipLaunchKernelGGL(ct_reset_sfx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, mask, obs);
-    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+    return ok_or_ehip();
+}
+
+int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream)
+{
+    const int64_t total = st.N * (int64_t)st.D;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(ct_received_sfx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, out);
+    return ok_or_ehip();
 }

@@ -110,6 +110,7 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
     const int64_t max_bytes = (int64_t)cfg->mac_header_bytes + cfg->net_header_bytes + cfg->counter_bound + 64;
     k.fast_div = (!no_fast && gw_fast_div_ok(tab.data_rate, max_bytes)) ? 1 : 0;
     // round(err)/bits <= 0.25  <=>  4*round(err) <= bits  when bits is an integer (both < 2^53)
+    k.cls_limit = (no_fast || getenv("GW_NO_CLASSES")) ? 0.0 : 1.0e6;
     k.fast_decide = (!no_fast && cfg->max_ber == 0.25 && tab.coded_factor * 8.0 == floor(tab.coded_factor * 8.0)) ? 1 : 0;
     k.idem_states = 1;                              // hearing the same talker twice changes nothing more
     for (int to = 0; to < R && k.idem_states; ++to)
@@ -127,7 +128,7 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
                 int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
-    return env->st.tau ? gw_launch_step_sfx(env->st, device, duration, obs, reward, done, stream)
+    return env->st.tk ? gw_launch_step_sfx(env->st, device, duration, obs, reward, done, stream)
                       : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
 
@@ -255,31 +256,36 @@ int gw_create(const gw_config* cfg, gw_env** out)
     GwDevConst* d_cst = nullptr; uint8_t* d_trans = nullptr; double* d_ber = nullptr;
     const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
 #define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
-    TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);
-    if (cfg->flags & GW_CFG_EXPLICIT_QUEUE) TRY_ALLOC(st.counter, N);
-    if (cfg->flags & GW_CFG_EXPLICIT_QUEUE) {
+    const bool explicit_q = (cfg->flags & GW_CFG_EXPLICIT_QUEUE) != 0;
+    uint8_t* d_cls = nullptr;
+    if (explicit_q) {
+        TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
         TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
+        TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
+        TRY_ALLOC(st.rxs, N * R);
     } else {
-        TRY_ALLOC(st.qlen, N * D);  TRY_ALLOC(st.tau, N);  TRY_ALLOC(st.nbp, N);
-        TRY_ALLOC(st.bpc, N);       TRY_ALLOC(st.bpp, N);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
+        if (N > (1ll << 27)) { gw_destroy(env); return fail(GW_EUNSUPPORTED, "num_envs > 2^27 needs GW_CFG_EXPLICIT_QUEUE"); }
+        st.RB = 16 * ((2 * D + 1 + 15) / 16);
+        TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);     TRY_ALLOC(st.ip, N * 4);
+        TRY_ALLOC(st.qb, N * st.RB);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
     }
-    TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
-    TRY_ALLOC(st.rxs, N * R);  TRY_ALLOC(st.flags, N);
+    TRY_ALLOC(st.flags, N);
     if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
     TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
-    TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount);  TRY_ALLOC(d_ber, tcount);
+    TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
 #undef TRY_ALLOC
-    st.cst = d_cst; st.trans = d_trans; st.ber = d_ber;
+    st.cst = d_cst; st.trans = d_trans; st.ber = d_ber; st.cls = d_cls;
 
 #define HIP_TRY_D(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rc = fail(GW_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); gw_destroy(env); return rc; } } while (0)
     HIP_TRY_D(hipMemcpy(d_cst, &k, sizeof k, hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_trans, env->tab.trans, tcount * sizeof(uint8_t), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_ber, env->tab.ber, tcount * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_D(hipMemcpy(d_cls, env->tab.cls, tcount * sizeof(uint8_t), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
     if (st.bph) HIP_TRY_D(hipMemset(st.bph, 0, (size_t)N * GW_RING_PHYS * sizeof(GwBp)));
-    rc = gw_launch_init(st, nullptr);
+    rc = explicit_q ? gw_launch_init(st, nullptr) : gw_launch_init_sfx(st, nullptr);
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
     HIP_TRY_D(hipDeviceSynchronize());
 #undef HIP_TRY_D
@@ -301,7 +307,7 @@ int gw_reset(gw_env* env, const uint8_t* mask_dev, int32_t* obs_dev, void* strea
     if (!env) return fail(GW_EINVAL, "env is NULL");
     int rc = select_device(env);
     if (rc) return rc;
-    if (env->st.tau ? gw_launch_reset_sfx(env->st, mask_dev, obs_dev, stream)
+    if (env->st.tk ? gw_launch_reset_sfx(env->st, mask_dev, obs_dev, stream)
                     : gw_launch_reset(env->st, mask_dev, obs_dev, stream))
         return fail(GW_EHIP, "reset kernel launch failed");
     return GW_OK;
@@ -343,7 +349,8 @@ int gw_received(gw_env* env, int32_t* out_dev, void* stream)
     if (!env || !out_dev) return fail(GW_EINVAL, "env/out is NULL");
     int rc = select_device(env);
     if (rc) return rc;
-    if (gw_launch_received(env->st, out_dev, stream)) return fail(GW_EHIP, "received kernel launch failed");
+    if (env->st.tk ? gw_launch_received_sfx(env->st, out_dev, stream) : gw_launch_received(env->st, out_dev, stream))
+        return fail(GW_EHIP, "received kernel launch failed");
     return GW_OK;
 }
 
@@ -494,6 +501,81 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
 #define NEED(count, type) do { if (bytes != (size_t)(count) * sizeof(type)) \
         return fail(GW_EFIELD, "field %s needs %zu bytes, got %zu", field, (size_t)(count) * sizeof(type), bytes); } while (0)
 
+    if (st.tk) {                                     // ---- suffix mode: packed records (ct_step_sfx.hip) ----
+        if (!strcmp(field, "flags")) { NEED(N, uint32_t); HIP_TRY(hipMemcpy(dst, st.flags, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
+        static const char* pes[5] = {"n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped"};
+        for (int k = 0; k < 5; ++k)
+            if (!strcmp(field, pes[k])) {
+                if (!st.pe_stats) return fail(GW_EFIELD, "field %s needs GW_CFG_PER_ENV_STATS", field);
+                NEED(N, uint64_t);
+                HIP_TRY(hipMemcpy(dst, st.pe_stats + (size_t)k * N, bytes, hipMemcpyDeviceToHost));
+                return GW_OK;
+            }
+        const int RB = st.RB;
+        std::vector<double> tw((size_t)N * 2);
+        std::vector<uint32_t> tk((size_t)N * 4), ip((size_t)N * 4);
+        std::vector<uint8_t> qb((size_t)N * RB);
+        HIP_TRY(hipMemcpy(tw.data(), st.tw, tw.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tk.data(), st.tk, tk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ip.data(), st.ip, ip.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(qb.data(), st.qb, qb.size(), hipMemcpyDeviceToHost));
+        const uint32_t bound = (uint32_t)env->cfg.counter_bound;
+        const int pv = env->cfg.payload_value;
+        if (!strcmp(field, "now")) { NEED(N, double); double* o = (double*)dst; for (int64_t e = 0; e < N; ++e) o[e] = tw[e * 2]; return GW_OK; }
+        if (!strcmp(field, "wake")) {
+            NEED(N * D, double); double* o = (double*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = tw[e * 2 + 1];
+            return GW_OK;
+        }
+        if (!strcmp(field, "counter")) {             // sender.counter == value of the next tick
+            NEED(N * D, uint32_t); uint32_t* o = (uint32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) {
+                const uint32_t v = gw_min_u32(tk[e * 4 + 3] + (tk[e * 4] - tk[e * 4 + 2]), bound);
+                for (int i = 0; i < D; ++i) o[e * D + i] = v;
+            }
+            return GW_OK;
+        }
+        if (!strcmp(field, "last_abs")) { NEED(N, int32_t); int32_t* o = (int32_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = (int32_t)(ip[e * 4 + 3] & 0x7fffffffu); return GW_OK; }
+        if (!strcmp(field, "latest_diff")) {
+            NEED(N, int32_t); int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) { const uint32_t m = ip[e * 4 + 2]; o[e] = pv * ((int)(m & 1u) - (int)((m >> 1) & 1u)); }
+            return GW_OK;
+        }
+        if (!strcmp(field, "received")) {
+            NEED(N * D, int32_t); int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ((ip[e * 4 + 2] >> i) & 1u) ? pv : 0;
+            return GW_OK;
+        }
+        if (!strcmp(field, "qlen")) {
+            NEED(N * D, int32_t); int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = qb[(size_t)e * RB + i];
+            return GW_OK;
+        }
+        if (!strcmp(field, "rx_power")) {
+            NEED(N * R, double); double* o = (double*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = env->tab.state_val[r][qb[(size_t)e * RB + D + r]];
+            return GW_OK;
+        }
+        if (!strcmp(field, "queue")) {
+            NEED(N * D * GW_QUEUE_CAP, uint32_t);
+            std::vector<GwBp> hist((size_t)N * GW_RING_PHYS);
+            HIP_TRY(hipMemcpy(hist.data(), st.bph, hist.size() * sizeof(GwBp), hipMemcpyDeviceToHost));
+            uint32_t* o = (uint32_t*)dst;
+            memset(o, 0, bytes);
+            const uint32_t base = (uint32_t)(env->cfg.mac_header_bytes + env->cfg.net_header_bytes);
+            for (int64_t e = 0; e < N; ++e) {
+                GwBp cur, prev;
+                cur.t0 = tk[e * 4 + 2]; cur.c0 = tk[e * 4 + 3];
+                prev.t0 = ip[e * 4]; prev.c0 = ip[e * 4 + 1];
+                for (int i = 0; i < D; ++i)
+                    expand_sfx(bound, base, (uint32_t)env->cfg.mult[i], qb[(size_t)e * RB + i], tk[e * 4], cur, prev,
+                               tk[e * 4 + 1], &hist[(size_t)e * GW_RING_PHYS], o + ((size_t)e * D + i) * GW_QUEUE_CAP);
+            }
+            return GW_OK;
+        }
+        return fail(GW_EFIELD, "unknown field %s", field);
+    }
+
     if (!strcmp(field, "now")) { NEED(N, double); HIP_TRY(hipMemcpy(dst, st.now, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
     if (!strcmp(field, "last_abs")) { NEED(N, int32_t); HIP_TRY(hipMemcpy(dst, st.last_abs, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
     if (!strcmp(field, "flags")) { NEED(N, uint32_t); HIP_TRY(hipMemcpy(dst, st.flags, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
@@ -526,43 +608,6 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
             int32_t* o = (int32_t*)dst;
             for (int64_t e = 0; e < N; ++e) o[e] = pv * ((int)(m[e] & 1u) - (int)((m[e] >> 1) & 1u));
         }
-        return GW_OK;
-    }
-    if ((!strcmp(field, "qlen") || !strcmp(field, "queue") || !strcmp(field, "counter")) && st.tau) {
-        std::vector<uint8_t> ql((size_t)N * D);
-        std::vector<uint32_t> tau(N), nbp(N);
-        std::vector<GwBp> cur(N), prev(N);
-        HIP_TRY(hipMemcpy(ql.data(), st.qlen, ql.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(tau.data(), st.tau, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(nbp.data(), st.nbp, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(cur.data(), st.bpc, N * sizeof(GwBp), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(prev.data(), st.bpp, N * sizeof(GwBp), hipMemcpyDeviceToHost));
-        const uint32_t bound = (uint32_t)env->cfg.counter_bound;
-        if (field[0] == 'c') {                       // sender.counter == value of the next tick
-            NEED(N * D, uint32_t);
-            uint32_t* o = (uint32_t*)dst;
-            for (int64_t e = 0; e < N; ++e) {
-                const uint32_t v = gw_min_u32(cur[e].c0 + (tau[e] - cur[e].t0), bound);
-                for (int i = 0; i < D; ++i) o[e * D + i] = v;
-            }
-            return GW_OK;
-        }
-        if (field[1] == 'l') {
-            NEED(N * D, int32_t);
-            int32_t* o = (int32_t*)dst;
-            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ql[(size_t)i * N + e];
-            return GW_OK;
-        }
-        NEED(N * D * GW_QUEUE_CAP, uint32_t);
-        std::vector<GwBp> hist((size_t)N * GW_RING_PHYS);
-        HIP_TRY(hipMemcpy(hist.data(), st.bph, hist.size() * sizeof(GwBp), hipMemcpyDeviceToHost));
-        uint32_t* o = (uint32_t*)dst;
-        memset(o, 0, bytes);
-        const uint32_t base = (uint32_t)(env->cfg.mac_header_bytes + env->cfg.net_header_bytes);
-        for (int64_t e = 0; e < N; ++e)
-            for (int i = 0; i < D; ++i)
-                expand_sfx(bound, base, (uint32_t)env->cfg.mult[i], ql[(size_t)i * N + e], tau[e], cur[e], prev[e],
-                           nbp[e], &hist[(size_t)e * GW_RING_PHYS], o + ((size_t)e * D + i) * GW_QUEUE_CAP);
         return GW_OK;
     }
     if (!strcmp(field, "qlen") || !strcmp(field, "queue")) {

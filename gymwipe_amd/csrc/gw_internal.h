@@ -23,6 +23,7 @@ struct GwDevConst {
     double  inv_slot;                   // RN(1/slot)
     double  fmod_limit;                 // fast fmod is used for t < fmod_limit
     double  rcp_data_rate;              // RN(1/data_rate)
+    double  cls_limit;                  // decode-certainty classes are valid for t < cls_limit
     int32_t fast_fmod, fast_div, fast_decide, idem_states;
 };
 
@@ -40,13 +41,13 @@ struct GwState {
     //  explicit (GW_CFG_EXPLICIT_QUEUE): a ring of packet byte sizes
     uint16_t* qhl;        // [D][N]     ring head (low byte) | length (high byte)
     uint32_t* ring;       // [N][D][GW_RING_PHYS]  packet byte sizes
-    //  suffix (default): see gw_queue.h -- one length byte per sender, tick counter + breakpoints per env
-    uint8_t*  qlen;       // [D][N]     packets in the queue of sender i
-    uint32_t* tau;        // [N]        counter ticks executed so far (index of the next tick)
-    uint32_t* nbp;        // [N]        breakpoints recorded so far
-    GwBp*     bpc;        // [N]        newest breakpoint  (tick, counter value)
-    GwBp*     bpp;        // [N]        second newest
-    GwBp*     bph;        // [N][GW_RING_PHYS]  ring of all breakpoints, entry j at [j & 127]
+    //  suffix (default): see gw_queue.h.  Packed so that one env costs four 16-byte loads:
+    double*   tw;         // [N][2]     {now, next counter tick}
+    uint32_t* tk;         // [N][4]     {tau = ticks so far, nbp = breakpoints so far, newest breakpoint (t0, c0)}
+    uint32_t* ip;         // [N][4]     {second newest breakpoint (t0, c0), rvmask, last_abs | done << 31}
+    uint8_t*  qb;         // [N][RB]    bytes: queue length of sender 0..D-1, rx-power state of radio 0..D, pad
+    GwBp*     bph;        // [N][GW_RING_PHYS]  ring of all breakpoints, entry j at [j & 127] (read only after >2 resets/100 ticks)
+    int32_t   RB;         //            bytes per qb record: 16 * ceil((2*D + 1) / 16)
     uint32_t* rvmask;     // [N]        bit i set <=> receivedValues[i] == payload_value
     int32_t*  last_abs;   // [N]        interpreter._lastAbsDifference
     uint8_t*  done;       // [N]        interpreter._done
@@ -59,7 +60,11 @@ struct GwState {
     const GwDevConst* cst;
     const uint8_t*    trans;     // [R to][R from][S]  state after hearing `from`
     const double*     ber;       // [R to][R from][S]  BER at `to` while hearing `from`, indexed by the NEW state
+    const uint8_t*    cls;       // [R to][R from][S]  decode certainty at `to` hearing `from` (GW_CLS_*), by the NEW state
 };
+
+// decode certainty of a link in a given noise state (host: gw_tables.cpp; valid while t < fmod_limit)
+enum { GW_CLS_COMPUTE = 0, GW_CLS_OK = 1, GW_CLS_HDR_FAIL = 2, GW_CLS_PAY_FAIL = 3 };
 
 enum { GW_T_STEPS = 0, GW_T_TX, GW_T_DELIV, GW_T_APP, GW_T_POP, GW_T_DROP, GW_T_FLAGS, GW_T_BAD, GW_T_COUNT };
 
@@ -74,6 +79,7 @@ struct GwHostTables {
     double state_val[GW_MAX_RADIOS][GW_MAX_NSTATES];  // mW; index 0 = thermal
     // flattened [to][from][s]
     uint8_t trans[GW_MAX_RADIOS * GW_MAX_RADIOS * GW_MAX_NSTATES];
+    uint8_t cls[GW_MAX_RADIOS * GW_MAX_RADIOS * GW_MAX_NSTATES];
     double  ber[GW_MAX_RADIOS * GW_MAX_RADIOS * GW_MAX_NSTATES];
 };
 
@@ -89,5 +95,7 @@ int gw_launch_received(const GwState& st, int32_t* out, void* stream);
 int gw_launch_step_sfx(const GwState& st, const int32_t* device, const int32_t* duration,
                        int32_t* obs, float* reward, uint8_t* done, void* stream);
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
+int gw_launch_init_sfx(const GwState& st, void* stream);
+int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream);
 
 #define GW_MAX_MULT        15          // packets per tick supported by the suffix encoding's ceil-div

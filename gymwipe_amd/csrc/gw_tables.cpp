@@ -48,6 +48,33 @@ double ber_bpsk(const gw_config& c, double sig_mw, double noise_mw)
     return (1 - pow(euler, -1.4 * x)) * pow(euler, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
 }
 
+// Decode certainty of a link with bit error rate `ber` (simple_stack.py:180-188,269-286).
+// Only claimed when the integer decision rule applies (maxBER == 0.25, integral coded bits):
+//   ok  <=>  4*round(err) <= codedBits,  err_hdr = ber*(t_h - t_s)*bitRate,
+//                                        err_pay = 2*ber*(t_e - t_h)*bitRate   (counted twice).
+// The event-time differences equal the nominal durations up to f64 rounding of times below
+// fmod_limit (< 1.2e6 s): relative 1e-6 for the header, 1e-5 for payloads of >= 1 byte.  With
+// |round(x) - x| <= 0.5 the outcome is CERTAIN for every payload size p >= 1 when
+//   header : 4*(ber*hd*br*(1+1e-6) + 0.5) <= Hb            (ok)   /  4*(ber*hd*br*(1-1e-6) - 0.5) > Hb  (fail)
+//   payload: p*(8cf - 64*ber*(br/dr)*(1+1e-5)) >= 2 at p=1  (ok)   /  p*(64*ber*(br/dr)*(1-1e-5) - 8cf) > 2 (fail)
+// Anything else stays GW_CLS_COMPUTE and is decided by the exact arithmetic in the kernel.
+uint8_t decode_class(const gw_config& c, const GwHostTables& t, double ber)
+{
+    const double cf = t.coded_factor, dr = t.data_rate, br = c.bit_rate;
+    if (!(c.max_ber == 0.25) || cf * 8.0 != floor(cf * 8.0)) return GW_CLS_COMPUTE;
+    const double hb = (double)(c.mac_header_bytes * 8);
+    const double Hb = hb * cf, hd = hb / dr;
+    const double eh = ber * hd * br;
+    const bool hdr_ok = 4.0 * (eh * (1 + 1e-6) + 0.5) <= Hb * (1 - 1e-12);
+    const bool hdr_fail = 4.0 * (eh * (1 - 1e-6) - 0.5) > Hb * (1 + 1e-12);
+    if (hdr_fail) return GW_CLS_HDR_FAIL;
+    if (!hdr_ok) return GW_CLS_COMPUTE;
+    const double g = 64.0 * ber * (br / dr);
+    if (8.0 * cf - g * (1 + 1e-5) >= 2.0 * (1 + 1e-12)) return GW_CLS_OK;
+    if (g * (1 - 1e-5) - 8.0 * cf > 2.0 * (1 + 1e-12)) return GW_CLS_PAY_FAIL;
+    return GW_CLS_COMPUTE;
+}
+
 } // namespace
 
 int gw_build_tables(const gw_config& cfg, GwHostTables& t, char* msg, size_t msglen)
@@ -102,7 +129,9 @@ int gw_build_tables(const gw_config& cfg, GwHostTables& t, char* msg, size_t msg
                     snprintf(msg, msglen, "negative noise power for radio %d (the reference asserts here)", j);
                     return GW_EUNSUPPORTED;
                 }
-                t.ber[((size_t)j * R + i) * GW_MAX_NSTATES + s] = ber_bpsk(cfg, t.prx[i][j], noise);
+                const size_t at = ((size_t)j * R + i) * GW_MAX_NSTATES + s;
+                t.ber[at] = ber_bpsk(cfg, t.prx[i][j], noise);
+                t.cls[at] = decode_class(cfg, t, t.ber[at]);
             }
         }
     }

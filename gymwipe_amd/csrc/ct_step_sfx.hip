@@ -60,7 +60,7 @@ __device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls
 
 // NW = 16-byte words of the qb record held in registers (1 for D <= 7); NW == 0: bytes stay in memory
 template <int DT, bool PER_ENV_STATS>
-__global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
+__global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
                                                          const int32_t* __restrict__ device,
                                                          const int32_t* __restrict__ duration,
                                                          int32_t* __restrict__ obs,
@@ -70,13 +70,22 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
     constexpr bool PACKED = (DT > 0 && DT <= 7);         // the whole byte record fits one uint4
     const uint32_t N = (uint32_t)st.N;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    const GwDevConst& c = *st.cst;
     const int D = DT > 0 ? DT : c.D;
-    const int R = D + 1, S = c.S, RRM = D;
+    const int R = D + 1, RRM = D;
+    constexpr int S = GW_MAX_NSTATES;
     const uint32_t RB = PACKED ? 16u : (uint32_t)st.RB;
+
+    // ---- lookup tables -> LDS (a few hundred bytes for D = 4); overlaps the state loads below ----
+    constexpr int DM = DT > 0 ? DT : GW_MAX_DEVICES;
+    __shared__ uint8_t s_trans[(DM + 1) * (DM + 1) * S];
+    __shared__ double  s_ber[2 * DM * S];
+    __shared__ uint8_t s_cls[2 * DM * S];
+    for (int i = threadIdx.x; i < R * R * S; i += blockDim.x) s_trans[i] = st.trans[i];
+    for (int i = threadIdx.x; i < 2 * D * S; i += blockDim.x) { s_ber[i] = st.ber2[i]; s_cls[i] = st.cls2[i]; }
 
     Tally k = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
+    __syncthreads();
 
     if (e < N) {
         const int d = device[e];
@@ -132,16 +141,12 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             bpp.t0 = ip.x; bpp.c0 = ip.y;
             const GwBp* hist = st.bph + ((size_t)e << 7);
             // what the addressed sender / the RRM become after hearing the RRM / sender d once
-            const uint32_t ia = (uint32_t)((d * R + RRM) * S) + s_d_old;
-            const uint32_t s_d = st.trans[ia];
-            const uint32_t ja = (uint32_t)((d * R + RRM) * S) + s_d;
-            const double ber_a = st.ber[ja];
-            const uint32_t cls_a = st.cls[ja];
-            const uint32_t ix = (uint32_t)((RRM * R + d) * S) + s_r_old;
-            const uint32_t s_r1 = st.trans[ix];
-            const uint32_t jx = (uint32_t)((RRM * R + d) * S) + s_r1;
-            const double ber_x1 = st.ber[jx];
-            const uint32_t cls_x1 = st.cls[jx];
+            const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];
+            const double ber_a = s_ber[(uint32_t)(d * S) + s_d];
+            const uint32_t cls_a = s_cls[(uint32_t)(d * S) + s_d];
+            const uint32_t s_r1 = s_trans[(uint32_t)((RRM * R + d) * S) + s_r_old];
+            const double ber_x1 = s_ber[(uint32_t)((D + d) * S) + s_r1];
+            const uint32_t cls_x1 = s_cls[(uint32_t)((D + d) * S) + s_r1];
             uint32_t s_r = s_r_old;
             const uint32_t mult_d = (uint32_t)c.mult[d];
             const uint32_t inv16_d = c.inv16[d];
@@ -213,9 +218,9 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
                     if (idem) {
                         s_r = s_r1;
                     } else {
-                        s_r = st.trans[(uint32_t)((RRM * R + d) * S) + s_r];
-                        ber_x = st.ber[(uint32_t)((RRM * R + d) * S) + s_r];
-                        cls_x = st.cls[(uint32_t)((RRM * R + d) * S) + s_r];
+                        s_r = s_trans[(uint32_t)((RRM * R + d) * S) + s_r];
+                        ber_x = s_ber[(uint32_t)((D + d) * S) + s_r];
+                        cls_x = s_cls[(uint32_t)((D + d) * S) + s_r];
                     }
                     const bool ok = decode(m, cls_x, cls_valid, ber_x, x, br, hdr_bits,
                                            (double)(pay * 8) * c.coded_factor, fl);
@@ -240,9 +245,9 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st,
             // ---- every other sender saw the same n_ticks ticks; every other radio heard the
             //      announcement and, if any, d's data (simple_stack.py:130-157) ------------------
             auto heard = [&](int j, uint32_t s0) {
-                uint32_t s = st.trans[(uint32_t)((j * R + RRM) * S) + s0];
+                uint32_t s = s_trans[(uint32_t)((j * R + RRM) * S) + s0];
                 for (int n = 0; n < n_data; ++n) {
-                    const uint32_t s2 = st.trans[(uint32_t)((j * R + d) * S) + s];
+                    const uint32_t s2 = s_trans[(uint32_t)((j * R + d) * S) + s];
                     if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
                     s = s2;
                 }
@@ -368,17 +373,17 @@ __global__ void ct_received_sfx_kernel(GwState st, int32_t* __restrict__ out)
 }
 
 template <int DT>
-int launch(const GwState& st, const int32_t* device, const int32_t* duration,
+int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
            int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
     const unsigned blk = (unsigned)st.block;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
     if (st.pe_stats)
         hipLaunchKernelGGL((ct_step_sfx_kernel<DT, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, device, duration, obs, reward, done);
+                           st, cst, device, duration, obs, reward, done);
     else
         hipLaunchKernelGGL((ct_step_sfx_kernel<DT, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, device, duration, obs, reward, done);
+                           st, cst, device, duration, obs, reward, done);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
@@ -386,15 +391,15 @@ inline int ok_or_ehip() { return hipGetLastError() == hipSuccess ? GW_OK : GW_EH
 
 } // namespace
 
-int gw_launch_step_sfx(const GwState& st, const int32_t* device, const int32_t* duration,
+int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
                        int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
     switch (st.D) {
-    case 2:  return launch<2>(st, device, duration, obs, reward, done, stream);
-    case 3:  return launch<3>(st, device, duration, obs, reward, done, stream);
-    case 4:  return launch<4>(st, device, duration, obs, reward, done, stream);
-    case 6:  return launch<6>(st, device, duration, obs, reward, done, stream);
-    default: return launch<0>(st, device, duration, obs, reward, done, stream);
+    case 2:  return launch<2>(st, cst, device, duration, obs, reward, done, stream);
+    case 3:  return launch<3>(st, cst, device, duration, obs, reward, done, stream);
+    case 4:  return launch<4>(st, cst, device, duration, obs, reward, done, stream);
+    case 6:  return launch<6>(st, cst, device, duration, obs, reward, done, stream);
+    default: return launch<0>(st, cst, device, duration, obs, reward, done, stream);
     }
 }
 

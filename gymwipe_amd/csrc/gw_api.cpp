@@ -128,7 +128,7 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
                 int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
-    return env->st.tk ? gw_launch_step_sfx(env->st, device, duration, obs, reward, done, stream)
+    return env->st.tk ? gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, stream)
                       : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
 
@@ -257,7 +257,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
 #define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
     const bool explicit_q = (cfg->flags & GW_CFG_EXPLICIT_QUEUE) != 0;
-    uint8_t* d_cls = nullptr;
+    uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr;
     if (explicit_q) {
         TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
         TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
@@ -274,14 +274,30 @@ int gw_create(const gw_config* cfg, gw_env** out)
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
     TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
     TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
+    TRY_ALLOC(d_ber2, 2 * D * GW_MAX_NSTATES);  TRY_ALLOC(d_cls2, 2 * D * GW_MAX_NSTATES);
 #undef TRY_ALLOC
-    st.cst = d_cst; st.trans = d_trans; st.ber = d_ber; st.cls = d_cls;
+    st.cst = d_cst; st.trans = d_trans; st.ber = d_ber; st.cls = d_cls; st.ber2 = d_ber2; st.cls2 = d_cls2;
 
 #define HIP_TRY_D(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rc = fail(GW_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); gw_destroy(env); return rc; } } while (0)
     HIP_TRY_D(hipMemcpy(d_cst, &k, sizeof k, hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_trans, env->tab.trans, tcount * sizeof(uint8_t), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_ber, env->tab.ber, tcount * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY_D(hipMemcpy(d_cls, env->tab.cls, tcount * sizeof(uint8_t), hipMemcpyHostToDevice));
+    {
+        std::vector<double> b2((size_t)2 * D * GW_MAX_NSTATES);
+        std::vector<uint8_t> c2((size_t)2 * D * GW_MAX_NSTATES);
+        for (int dd = 0; dd < D; ++dd)
+            for (int ss = 0; ss < GW_MAX_NSTATES; ++ss) {
+                const size_t ann = ((size_t)dd * R + D) * GW_MAX_NSTATES + ss;      // to = dd, from = RRM
+                const size_t dat = ((size_t)D * R + dd) * GW_MAX_NSTATES + ss;      // to = RRM, from = dd
+                b2[(size_t)dd * GW_MAX_NSTATES + ss] = env->tab.ber[ann];
+                c2[(size_t)dd * GW_MAX_NSTATES + ss] = env->tab.cls[ann];
+                b2[((size_t)D + dd) * GW_MAX_NSTATES + ss] = env->tab.ber[dat];
+                c2[((size_t)D + dd) * GW_MAX_NSTATES + ss] = env->tab.cls[dat];
+            }
+        HIP_TRY_D(hipMemcpy(d_ber2, b2.data(), b2.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY_D(hipMemcpy(d_cls2, c2.data(), c2.size(), hipMemcpyHostToDevice));
+    }
     HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
     if (st.bph) HIP_TRY_D(hipMemset(st.bph, 0, (size_t)N * GW_RING_PHYS * sizeof(GwBp)));

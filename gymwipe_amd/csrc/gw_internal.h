@@ -61,6 +61,10 @@ struct GwState {
     const uint8_t*    trans;     // [R to][R from][S]  state after hearing `from`
     const double*     ber;       // [R to][R from][S]  BER at `to` while hearing `from`, indexed by the NEW state
     const uint8_t*    cls;       // [R to][R from][S]  decode certainty at `to` hearing `from` (GW_CLS_*), by the NEW state
+    // compact slices of ber/cls the step actually needs, staged in LDS by the suffix kernel:
+    //   [0][d][s]: sender d hearing the RRM's announcement;  [1][d][s]: the RRM hearing sender d
+    const double*     ber2;      // [2][D][S]
+    const uint8_t*    cls2;      // [2][D][S]
 };
 
 // decode certainty of a link in a given noise state (host: gw_tables.cpp; valid while t < fmod_limit)
@@ -92,7 +96,7 @@ int gw_launch_reset(const GwState& st, const uint8_t* mask, int32_t* obs, void* 
 int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* duration,
                    int32_t* obs, float* reward, uint8_t* done, void* stream);
 int gw_launch_received(const GwState& st, int32_t* out, void* stream);
-int gw_launch_step_sfx(const GwState& st, const int32_t* device, const int32_t* duration,
+int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
                        int32_t* obs, float* reward, uint8_t* done, void* stream);
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
 int gw_launch_init_sfx(const GwState& st, void* stream);

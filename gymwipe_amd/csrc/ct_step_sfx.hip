@@ -75,23 +75,56 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     constexpr int S = GW_MAX_NSTATES;
     const uint32_t RB = PACKED ? 16u : (uint32_t)st.RB;
 
-    // ---- lookup tables -> LDS (a few hundred bytes for D = 4); overlaps the state loads below ----
+    // ---- lookup tables -> LDS (a few hundred bytes for D = 4).  Their global loads are issued FIRST,
+    //      the per-env state loads right behind them, and only then are the tables written to LDS,
+    //      so that both HBM/L2 latencies overlap (vmcnt is in-order: waiting for the older table
+    //      loads does not wait for the younger state loads).
     constexpr int DM = DT > 0 ? DT : GW_MAX_DEVICES;
-    __shared__ uint8_t s_trans[(DM + 1) * (DM + 1) * S];
-    __shared__ double  s_ber[2 * DM * S];
-    __shared__ uint8_t s_cls[2 * DM * S];
-    for (int i = threadIdx.x; i < R * R * S; i += blockDim.x) s_trans[i] = st.trans[i];
-    for (int i = threadIdx.x; i < 2 * D * S; i += blockDim.x) { s_ber[i] = st.ber2[i]; s_cls[i] = st.cls2[i]; }
+    constexpr int TRANS_B = ((DM + 1) * (DM + 1) * S + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_trans[TRANS_B];
+    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DM * S];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DM * S];
+    const int n_tr = (R * R * S + 15) >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;   // 16-B chunks
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const bool one_pass = PACKED && nthr >= 64;          // D <= 7: every table fits one chunk per thread
+    uint4 r_tr = make_uint4(0u, 0u, 0u, 0u), r_be = r_tr, r_cl = r_tr;
+    if (one_pass) {
+        if (tid < n_tr) r_tr = ld<uint4>(st.trans, (uint32_t)tid << 4);
+        if (tid < n_be) r_be = ld<uint4>(st.ber2, (uint32_t)tid << 4);
+        if (tid < n_cl) r_cl = ld<uint4>(st.cls2, (uint32_t)tid << 4);
+    }
 
     Tally k = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
+
+    // ---- per-env state loads (before anything is stored) ---------------------------------------
+    const bool live = e < N;
+    const uint32_t o16 = e << 4;
+    const uint32_t oq = e * RB;
+    int d = 0, du = 0;
+    uint4 ip = make_uint4(0u, 0u, 0u, 0u), tk = ip, qw = ip;
+    double2 tw = make_double2(0.0, 0.0);
+    if (live) {
+        d = device[e];
+        du = duration[e];
+        ip = ld<uint4>(st.ip, o16);
+        tw = ld<double2>(st.tw, o16);
+        tk = ld<uint4>(st.tk, o16);
+        if (PACKED) qw = ld<uint4>(st.qb, oq);
+    }
+
+    if (one_pass) {
+        if (tid < n_tr) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)tid << 4)) = r_tr;
+        if (tid < n_be) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)tid << 4)) = r_be;
+        if (tid < n_cl) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)tid << 4)) = r_cl;
+    } else {
+        for (int i = tid; i < n_tr; i += nthr) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)i << 4)) = ld<uint4>(st.trans, (uint32_t)i << 4);
+        for (int i = tid; i < n_be; i += nthr) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)i << 4)) = ld<uint4>(st.ber2, (uint32_t)i << 4);
+        for (int i = tid; i < n_cl; i += nthr) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)i << 4)) = ld<uint4>(st.cls2, (uint32_t)i << 4);
+    }
     __syncthreads();
 
-    if (e < N) {
-        const int d = device[e];
-        const int du = duration[e];
-        const uint32_t o16 = e << 4;
-        const uint4 ip = ld<uint4>(st.ip, o16);
+    if (live) {
         uint32_t rvm = ip.z;
         int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
         uint32_t dn = ip.w >> 31;
@@ -117,14 +150,8 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             const int mh = c.mac_hdr;
             const bool idem = c.idem_states != 0;
 
-            // ---- every load of the step is issued up here, before anything is stored ------------
-            const double2 tw = ld<double2>(st.tw, o16);
-            const uint4 tk = ld<uint4>(st.tk, o16);
-            const uint32_t oq = e * RB;
-            uint4 qw = make_uint4(0u, 0u, 0u, 0u);
             uint32_t len_d, s_d_old, s_r_old;
             if (PACKED) {
-                qw = ld<uint4>(st.qb, oq);
                 len_d = byte_of(qw, (uint32_t)d);
                 s_d_old = byte_of(qw, (uint32_t)(DT + d));
                 s_r_old = byte_of(qw, (uint32_t)(2 * DT));

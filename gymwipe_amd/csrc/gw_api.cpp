@@ -273,8 +273,8 @@ int gw_create(const gw_config* cfg, gw_env** out)
     if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
     TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
-    TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
-    TRY_ALLOC(d_ber2, 2 * D * GW_MAX_NSTATES);  TRY_ALLOC(d_cls2, 2 * D * GW_MAX_NSTATES);
+    TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount + 16);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
+    TRY_ALLOC(d_ber2, 2 * D * GW_MAX_NSTATES + 2);  TRY_ALLOC(d_cls2, 2 * D * GW_MAX_NSTATES + 16);
 #undef TRY_ALLOC
     st.cst = d_cst; st.trans = d_trans; st.ber = d_ber; st.cls = d_cls; st.ber2 = d_ber2; st.cls2 = d_cls2;
 

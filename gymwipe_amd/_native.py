@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libgymwipe_amd.so")
+LIB_PATH = os.environ.get("GW_LIB") or os.path.join(_PKG, "lib", "libgymwipe_amd.so")   # GW_LIB: diagnostic builds
 CSRC = os.path.join(_PKG, "csrc")
 
 ABI_VERSION = 1

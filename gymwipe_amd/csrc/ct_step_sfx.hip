@@ -22,6 +22,22 @@
 
 using namespace gwk;
 
+// In-kernel stamps: only in the diagnostic build (make STAMPS=1 -> libgymwipe_amd_stamps.so); the
+// product library contains no stamp code.  Values go to a buffer nothing else reads.
+#ifdef GW_STAMPS
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long _t;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if ((threadIdx.x & 63) == 0)                                                          \
+            st.stamps[(((size_t)blockIdx.x * ((blockDim.x + 63) >> 6)) + (threadIdx.x >> 6)) * 8 + (i)] = _t; \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 template <class T>
@@ -79,6 +95,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     //      the per-env state loads right behind them, and only then are the tables written to LDS,
     //      so that both HBM/L2 latencies overlap (vmcnt is in-order: waiting for the older table
     //      loads does not wait for the younger state loads).
+    STAMP(0);
     constexpr int DM = DT > 0 ? DT : GW_MAX_DEVICES;
     constexpr int TRANS_B = ((DM + 1) * (DM + 1) * S + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_trans[TRANS_B];
@@ -123,9 +140,12 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         for (int i = tid; i < n_cl; i += nthr) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)i << 4)) = ld<uint4>(st.cls2, (uint32_t)i << 4);
     }
     __syncthreads();
+    STAMP(1);
 
     if (live) {
         uint32_t rvm = ip.z;
+        if (rvm == 0xdeadbeefu) fl_new = 1;   // touches ip: the stamp below sits after the state loads have landed
+        STAMP(2);
         int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
         uint32_t dn = ip.w >> 31;
         const int pv = c.payload_value;
@@ -190,6 +210,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
+            STAMP(3);
             // ---- A.3: window at sender d ------------------------------------------------------
             uint32_t tau = tau0;
             int n_data = 0;
@@ -263,6 +284,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 }
             }
 
+            STAMP(4);
             // ---- A.5: remaining ticks up to the end of the step -------------------------------
             ticks_to(t_end, true);
             const uint32_t n_ticks = tau - tau0;
@@ -314,6 +336,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 if (s_r != s_r_old) st.qb[oq + (uint32_t)(2 * D)] = (uint8_t)s_r;
             }
 
+            STAMP(5);
             // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
             const int32_t abs_d = latest < 0 ? -latest : latest;
@@ -338,7 +361,9 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         if (fl) st.flags[e] |= fl;                                         // rare: sticky flags
         fl_new = fl;
     }
+    STAMP(6);
     publish_totals(st.totals, k, k_steps, k_bad, fl_new);
+    STAMP(7);
 }
 
 // fresh env: counters 1 (counter_traffic.py:48) == breakpoint (tick 0, value 1); first tick at t = 0;

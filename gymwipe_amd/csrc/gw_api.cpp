@@ -273,6 +273,9 @@ int gw_create(const gw_config* cfg, gw_env** out)
     if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
     TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
+#ifdef GW_STAMPS
+    TRY_ALLOC(st.stamps, st.n_slots * 8);
+#endif
     TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount + 16);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
     TRY_ALLOC(d_ber2, 2 * D * GW_MAX_NSTATES + 2);  TRY_ALLOC(d_cls2, 2 * D * GW_MAX_NSTATES + 16);
 #undef TRY_ALLOC
@@ -517,6 +520,13 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
 #define NEED(count, type) do { if (bytes != (size_t)(count) * sizeof(type)) \
         return fail(GW_EFIELD, "field %s needs %zu bytes, got %zu", field, (size_t)(count) * sizeof(type), bytes); } while (0)
 
+#ifdef GW_STAMPS
+    if (!strcmp(field, "stamps")) {
+        NEED(st.n_slots * 8, uint64_t);
+        HIP_TRY(hipMemcpy(dst, st.stamps, bytes, hipMemcpyDeviceToHost));
+        return GW_OK;
+    }
+#endif
     if (st.tk) {                                     // ---- suffix mode: packed records (ct_step_sfx.hip) ----
         if (!strcmp(field, "flags")) { NEED(N, uint32_t); HIP_TRY(hipMemcpy(dst, st.flags, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
         static const char* pes[5] = {"n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped"};

@@ -57,6 +57,7 @@ struct GwState {
     unsigned long long* totals;  // [n_slots][GW_T_COUNT], one 64-B slot per wave of the step launch:
                                  // steps, tx, delivered, appended, popped, dropped, flags_or, bad_actions
     int64_t   n_slots;
+    unsigned long long* stamps;  // diagnostic build only (make STAMPS=1): [n_slots][8] s_memtime stamps of the last launch
     const GwDevConst* cst;
     const uint8_t*    trans;     // [R to][R from][S]  state after hearing `from`
     const double*     ber;       // [R to][R from][S]  BER at `to` while hearing `from`, indexed by the NEW state

@@ -88,28 +88,40 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v, int width = 64)
 }
 
 
-// Event totals.  Each wave owns one 64-byte slot (GW_T_COUNT u64 words) and adds to it without
-// contention; gw_stats_read sums the slots on the host.  (A single shared line was measured to
-// serialise the whole launch: 8 K same-line atomics ~ 90 us on MI355X.)
+// Event totals.  Each wave owns one 64-byte slot (GW_T_COUNT u64 words); gw_stats_read sums the
+// slots on the host.  Measured on MI355X: eight atomics per wave on ONE shared line serialised the
+// whole launch (~90 us); eight 64-lane reductions + a load/add/store of the private slot still cost
+// 43% of the wave's cycles.  So: counters are packed into three lane words (per-lane values are
+// small), reduced with three shuffles trees, and added with fire-and-forget atomics on the wave's
+// own line (no contention, no load round trip).
 __device__ __forceinline__ void publish_totals(unsigned long long* totals, const Tally& k, uint32_t k_steps,
                                                uint32_t k_bad, uint32_t fl_new)
 {
     const int w = blockDim.x < 64 ? (int)blockDim.x : 64;
-    const uint32_t t_tx = wave_sum(k.tx, w), t_dl = wave_sum(k.deliv, w), t_ap = wave_sum(k.app, w);
-    const uint32_t t_po = wave_sum(k.pop, w), t_dr = wave_sum(k.drop, w), t_bad = wave_sum(k_bad, w);
-    const uint32_t t_st = wave_sum(k_steps, w), t_fl = wave_or(fl_new, w);
+    // per lane: tx, deliv, pop <= ~64 -> 10-bit fields (wave sums < 2^16 each in 16-bit lanes of a u64)
+    const unsigned long long a = (unsigned long long)k.tx | ((unsigned long long)k.deliv << 16) |
+                                 ((unsigned long long)k.pop << 32) | ((unsigned long long)(k_steps | (k_bad << 8)) << 48);
+    const unsigned long long b = (unsigned long long)k.app | ((unsigned long long)k.drop << 32);
+    unsigned long long ra = a, rb = b;
+    uint32_t rf = fl_new;
+    for (int off = w >> 1; off > 0; off >>= 1) {
+        ra += __shfl_down(ra, off, 64);
+        rb += __shfl_down(rb, off, 64);
+        rf |= __shfl_down(rf, off, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
         const size_t waves_per_block = (blockDim.x + 63) >> 6;
         const size_t wave = (size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
         unsigned long long* t = totals + wave * GW_T_COUNT;
-        t[GW_T_STEPS] += t_st;
-        t[GW_T_TX] += t_tx;
-        t[GW_T_DELIV] += t_dl;
-        t[GW_T_APP] += t_ap;
-        t[GW_T_POP] += t_po;
-        t[GW_T_DROP] += t_dr;
-        t[GW_T_FLAGS] |= t_fl;
-        t[GW_T_BAD] += t_bad;
+        const unsigned long long sb = ra >> 48;
+        atomicAdd(&t[GW_T_STEPS], sb & 0xffull);
+        atomicAdd(&t[GW_T_TX], ra & 0xffffull);
+        atomicAdd(&t[GW_T_APP], rb & 0xffffffffull);
+        if ((ra >> 16) & 0xffffull) atomicAdd(&t[GW_T_DELIV], (ra >> 16) & 0xffffull);
+        if ((ra >> 32) & 0xffffull) atomicAdd(&t[GW_T_POP], (ra >> 32) & 0xffffull);
+        if (rb >> 32) atomicAdd(&t[GW_T_DROP], rb >> 32);
+        if (sb >> 8) atomicAdd(&t[GW_T_BAD], sb >> 8);
+        if (rf) atomicOr(&t[GW_T_FLAGS], (unsigned long long)rf);
     }
 }
 

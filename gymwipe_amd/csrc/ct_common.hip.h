@@ -88,40 +88,42 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v, int width = 64)
 }
 
 
-// Event totals.  Each wave owns one 64-byte slot (GW_T_COUNT u64 words); gw_stats_read sums the
-// slots on the host.  Measured on MI355X: eight atomics per wave on ONE shared line serialised the
-// whole launch (~90 us); eight 64-lane reductions + a load/add/store of the private slot still cost
-// 43% of the wave's cycles.  So: counters are packed into three lane words (per-lane values are
-// small), reduced with three shuffles trees, and added with fire-and-forget atomics on the wave's
-// own line (no contention, no load round trip).
+// Event totals.  Each wave owns one 64-byte slot (GW_T_COUNT u64 words) in HBM; gw_stats_read sums
+// the slots on the host.  What was measured on MI355X on the way here:
+//   * eight global atomics per wave on ONE shared line serialised the whole launch (~90 us);
+//   * eight 64-lane shuffle reductions + load/add/store of the private slot: 43% of a wave's cycles;
+//   * three packed shuffle reductions + atomics on the private line: still ~2.1k cycles per wave.
+// Now: the per-lane counters are packed into three words, summed by LDS atomics (one ds_add per
+// word for the whole wave), and lanes 0..7 issue ONE global atomic instruction on the wave's line.
 __device__ __forceinline__ void publish_totals(unsigned long long* totals, const Tally& k, uint32_t k_steps,
                                                uint32_t k_bad, uint32_t fl_new)
 {
-    const int w = blockDim.x < 64 ? (int)blockDim.x : 64;
-    // per lane: tx, deliv, pop <= ~64 -> 10-bit fields (wave sums < 2^16 each in 16-bit lanes of a u64)
-    const unsigned long long a = (unsigned long long)k.tx | ((unsigned long long)k.deliv << 16) |
-                                 ((unsigned long long)k.pop << 32) | ((unsigned long long)(k_steps | (k_bad << 8)) << 48);
-    const unsigned long long b = (unsigned long long)k.app | ((unsigned long long)k.drop << 32);
-    unsigned long long ra = a, rb = b;
-    uint32_t rf = fl_new;
-    for (int off = w >> 1; off > 0; off >>= 1) {
-        ra += __shfl_down(ra, off, 64);
-        rb += __shfl_down(rb, off, 64);
-        rf |= __shfl_down(rf, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ uint32_t s_acc[4][4];                    // [wave in block][word]
+    const uint32_t lane = threadIdx.x & 63u, wv = (threadIdx.x >> 6) & 3u;
+    if (lane < 4u) s_acc[wv][lane] = 0u;                // same wave, in-order LDS: no barrier needed
+    // wave sums: tx, deliv, pop < 2^10 each; app, drop < 2^15 each; steps, bad <= 64 each
+    atomicAdd(&s_acc[wv][0], k.tx | (k.deliv << 10) | (k.pop << 20));
+    atomicAdd(&s_acc[wv][1], k.app | (k.drop << 16));
+    atomicAdd(&s_acc[wv][2], k_steps | (k_bad << 8));
+    atomicOr(&s_acc[wv][3], fl_new);
+    if (lane < (uint32_t)GW_T_COUNT) {
+        const uint32_t a = s_acc[wv][0], b = s_acc[wv][1], c = s_acc[wv][2], f = s_acc[wv][3];
+        unsigned long long v = 0;
+        switch (lane) {
+        case GW_T_STEPS: v = c & 0xffu; break;
+        case GW_T_TX:    v = a & 0x3ffu; break;
+        case GW_T_DELIV: v = (a >> 10) & 0x3ffu; break;
+        case GW_T_APP:   v = b & 0xffffu; break;
+        case GW_T_POP:   v = (a >> 20) & 0x3ffu; break;
+        case GW_T_DROP:  v = b >> 16; break;
+        case GW_T_BAD:   v = (c >> 8) & 0xffu; break;
+        default:         v = 0; break;                  // GW_T_FLAGS handled below
+        }
         const size_t waves_per_block = (blockDim.x + 63) >> 6;
         const size_t wave = (size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
         unsigned long long* t = totals + wave * GW_T_COUNT;
-        const unsigned long long sb = ra >> 48;
-        atomicAdd(&t[GW_T_STEPS], sb & 0xffull);
-        atomicAdd(&t[GW_T_TX], ra & 0xffffull);
-        atomicAdd(&t[GW_T_APP], rb & 0xffffffffull);
-        if ((ra >> 16) & 0xffffull) atomicAdd(&t[GW_T_DELIV], (ra >> 16) & 0xffffull);
-        if ((ra >> 32) & 0xffffull) atomicAdd(&t[GW_T_POP], (ra >> 32) & 0xffffull);
-        if (rb >> 32) atomicAdd(&t[GW_T_DROP], rb >> 32);
-        if (sb >> 8) atomicAdd(&t[GW_T_BAD], sb >> 8);
-        if (rf) atomicOr(&t[GW_T_FLAGS], (unsigned long long)rf);
+        if (lane == GW_T_FLAGS) { if (f) atomicOr(&t[GW_T_FLAGS], (unsigned long long)f); }
+        else if (v) atomicAdd(&t[lane], v);
     }
 }
 

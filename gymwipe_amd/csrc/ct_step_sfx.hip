@@ -32,7 +32,7 @@ using namespace gwk;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");            \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         if ((threadIdx.x & 63) == 0)                                                          \
-            st.stamps[(((size_t)blockIdx.x * ((blockDim.x + 63) >> 6)) + (threadIdx.x >> 6)) * 8 + (i)] = _t; \
+            st.stamps[(((size_t)blockIdx.x * ((blockDim.x + 63) >> 6)) + (threadIdx.x >> 6)) * 16 + (i)] = _t; \
     } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -139,13 +139,14 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         for (int i = tid; i < n_be; i += nthr) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)i << 4)) = ld<uint4>(st.ber2, (uint32_t)i << 4);
         for (int i = tid; i < n_cl; i += nthr) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)i << 4)) = ld<uint4>(st.cls2, (uint32_t)i << 4);
     }
-    __syncthreads();
     STAMP(1);
+    __syncthreads();
+    STAMP(2);
 
     if (live) {
         uint32_t rvm = ip.z;
         if (rvm == 0xdeadbeefu) fl_new = 1;   // touches ip: the stamp below sits after the state loads have landed
-        STAMP(2);
+        STAMP(3);
         int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
         uint32_t dn = ip.w >> 31;
         const int pv = c.payload_value;
@@ -199,18 +200,20 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             const uint32_t inv16_d = c.inv16[d];
             const bool cls_valid = t_a < c.cls_limit;
 
+            STAMP(4);
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
             // ---- A.1 / A.2: announcement ------------------------------------------------------
             const int L = ndigits(slots);
             const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(L * 8)));
             k.tx++;
+            STAMP(5);
             const bool granted = decode(m, cls_a, cls_valid, ber_a, an, br, hdr_bits,
                                         (double)(L * 8) * c.coded_factor, fl);
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
-            STAMP(3);
+            STAMP(6);
             // ---- A.3: window at sender d ------------------------------------------------------
             uint32_t tau = tau0;
             int n_data = 0;
@@ -284,9 +287,10 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 }
             }
 
-            STAMP(4);
+            STAMP(7);
             // ---- A.5: remaining ticks up to the end of the step -------------------------------
             ticks_to(t_end, true);
+            STAMP(8);
             const uint32_t n_ticks = tau - tau0;
             k.app += kd.app;
             k.drop += kd.drop;
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 o.y = nb[4] | (nb[5] << 8) | (nb[6] << 16) | (nb[7] << 24);
                 o.z = nb[8] | (nb[9] << 8) | (nb[10] << 16) | (nb[11] << 24);
                 o.w = nb[12] | (nb[13] << 8) | (nb[14] << 16) | (nb[15] << 24);
+                STAMP(9);
                 st_(st.qb, oq, o);
             } else {
                 for (int i = 0; i < D; ++i) {
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 if (s_r != s_r_old) st.qb[oq + (uint32_t)(2 * D)] = (uint8_t)s_r;
             }
 
-            STAMP(5);
+            STAMP(10);
             // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
             const int32_t abs_d = latest < 0 ? -latest : latest;
@@ -361,9 +366,9 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         if (fl) st.flags[e] |= fl;                                         // rare: sticky flags
         fl_new = fl;
     }
-    STAMP(6);
+    STAMP(11);
     publish_totals(st.totals, k, k_steps, k_bad, fl_new);
-    STAMP(7);
+    STAMP(12);
 }
 
 // fresh env: counters 1 (counter_traffic.py:48) == breakpoint (tick 0, value 1); first tick at t = 0;

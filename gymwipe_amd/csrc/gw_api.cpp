@@ -274,7 +274,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
     TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
 #ifdef GW_STAMPS
-    TRY_ALLOC(st.stamps, st.n_slots * 8);
+    TRY_ALLOC(st.stamps, st.n_slots * 16);
 #endif
     TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount + 16);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
     TRY_ALLOC(d_ber2, 2 * D * GW_MAX_NSTATES + 2);  TRY_ALLOC(d_cls2, 2 * D * GW_MAX_NSTATES + 16);
@@ -522,7 +522,7 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
 
 #ifdef GW_STAMPS
     if (!strcmp(field, "stamps")) {
-        NEED(st.n_slots * 8, uint64_t);
+        NEED(st.n_slots * 16, uint64_t);
         HIP_TRY(hipMemcpy(dst, st.stamps, bytes, hipMemcpyDeviceToHost));
         return GW_OK;
     }

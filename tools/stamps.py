@@ -11,8 +11,9 @@ from gymwipe_amd import _native as nat
 N, D = 65536, 4
 env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
-names = ["start->tables issued+state issued+barrier", "barrier->state landed", "announcement", "window loop",
-         "tail ticks+others+qb store", "feedback+stores", "publish_totals"]
+names = ["0 issue table+state loads, write LDS", "1 barrier", "2 state landed (touch ip)", "3 unpack, LDS lookups, consts",
+         "4 announcement tx_times", "5 announcement decode, t_end", "6 window loop", "7 tail ticks_to(t_end)",
+         "8 other senders + pack", "9 qb store", "10 feedback + stores", "11 publish_totals"]
 rows = []
 env.reset()
 for k in range(48):
@@ -22,10 +23,10 @@ for k in range(48):
     torch.cuda.synchronize()
     if k >= 8:
         n_slots = (N + 15) // 16
-        out = np.empty((n_slots, 8), np.uint64)
+        out = np.empty((n_slots, 16), np.uint64)
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         w = out[: N // 64].astype(np.int64)
-        rows.append(np.diff(w, axis=1))
+        rows.append(np.diff(w[:, :13], axis=1))
 d = np.concatenate(rows)
 print("cycles per wave (s_memtime ticks), median / p90 / mean over %d waves x %d launches" % (N // 64, len(rows)))
 for i, n in enumerate(names):

@@ -75,7 +75,7 @@ __device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls
 }
 
 // NW = 16-byte words of the qb record held in registers (1 for D <= 7); NW == 0: bytes stay in memory
-template <int DT, bool PER_ENV_STATS>
+template <int DT>
 __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
                                                          const int32_t* __restrict__ device,
                                                          const int32_t* __restrict__ duration,
@@ -112,14 +112,15 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     }
 
     Tally k = {0, 0, 0, 0, 0};
-    uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
+    uint32_t k_bad = 0, k_steps = 0;
 
     // ---- per-env state loads (before anything is stored) ---------------------------------------
     const bool live = e < N;
     const uint32_t o16 = e << 4;
     const uint32_t oq = e * RB;
     int d = 0, du = 0;
-    uint4 ip = make_uint4(0u, 0u, 0u, 0u), tk = ip, qw = ip;
+    uint4 ip = make_uint4(0u, 0u, 0u, 0u), tk = ip, qw = ip, sa0 = ip, sa1 = ip;
+    const uint32_t o32 = e << 5;
     double2 tw = make_double2(0.0, 0.0);
     if (live) {
         d = device[e];
@@ -128,6 +129,8 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         tw = ld<double2>(st.tw, o16);
         tk = ld<uint4>(st.tk, o16);
         if (PACKED) qw = ld<uint4>(st.qb, oq);
+        sa0 = ld<uint4>(st.sa, o32);
+        sa1 = ld<uint4>(st.sa, o32 + 16u);
     }
 
     if (one_pass) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 
     if (live) {
         uint32_t rvm = ip.z;
-        if (rvm == 0xdeadbeefu) fl_new = 1;   // touches ip: the stamp below sits after the state loads have landed
+        if (rvm == 0xdeadbeefu) k_bad = 2;    // touches ip: the stamp below sits after the state loads have landed
         STAMP(3);
         int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
         uint32_t dn = ip.w >> 31;
@@ -355,19 +358,14 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             st_(st.tw, o16, make_double2(t_end, wake));
             st_(st.tk, o16, tau);                                         // only the tick counter changes
             st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
-            if (PER_ENV_STATS) {
-                st.pe_stats[0 * (size_t)N + e] += k.tx;
-                st.pe_stats[1 * (size_t)N + e] += k.deliv;
-                st.pe_stats[2 * (size_t)N + e] += k.app;
-                st.pe_stats[3 * (size_t)N + e] += k.pop;
-                st.pe_stats[4 * (size_t)N + e] += k.drop;
-            }
         }
-        if (fl) st.flags[e] |= fl;                                         // rare: sticky flags
-        fl_new = fl;
+        STAMP(11);
+        // ---- per-env event counters: {steps, tx, delivered, appended} {popped, dropped, bad, flags} ----
+        sa0.x += k_steps; sa0.y += k.tx; sa0.z += k.deliv; sa0.w += k.app;
+        sa1.x += k.pop;   sa1.y += k.drop; sa1.z += k_bad; sa1.w |= fl;
+        st_(st.sa, o32, sa0);
+        st_(st.sa, o32 + 16u, sa1);
     }
-    STAMP(11);
-    publish_totals(st.totals, k, k_steps, k_bad, fl_new);
     STAMP(12);
 }
 
@@ -384,8 +382,8 @@ __global__ void ct_init_sfx_kernel(GwState st)
     for (int b = 0; b < st.RB; ++b) st.qb[e * (uint32_t)st.RB + b] = 0;
     GwBp b0; b0.t0 = 0u; b0.c0 = 1u;
     st.bph[(size_t)e << 7] = b0;
-    st.flags[e] = 0u;
-    if (st.pe_stats) for (int s = 0; s < 5; ++s) st.pe_stats[(size_t)s * st.N + e] = 0ull;
+    st_(st.sa, e << 5, make_uint4(0u, 0u, 0u, 0u));
+    st_(st.sa, (e << 5) + 16u, make_uint4(0u, 0u, 0u, 0u));
 }
 
 // counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound.
@@ -435,12 +433,8 @@ int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, cons
 {
     const unsigned blk = (unsigned)st.block;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
-    if (st.pe_stats)
-        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, cst, device, duration, obs, reward, done);
-    else
-        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, cst, device, duration, obs, reward, done);
+    hipLaunchKernelGGL((ct_step_sfx_kernel<DT>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
+                       st, cst, device, duration, obs, reward, done);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 

@@ -268,11 +268,12 @@ int gw_create(const gw_config* cfg, gw_env** out)
         st.RB = 16 * ((2 * D + 1 + 15) / 16);
         TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);     TRY_ALLOC(st.ip, N * 4);
         TRY_ALLOC(st.qb, N * st.RB);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
+        TRY_ALLOC(st.sa, N * 8);
     }
-    TRY_ALLOC(st.flags, N);
-    if (cfg->flags & GW_CFG_PER_ENV_STATS) TRY_ALLOC(st.pe_stats, N * 5);
+    if (explicit_q) TRY_ALLOC(st.flags, N);
+    if (explicit_q && (cfg->flags & GW_CFG_PER_ENV_STATS)) TRY_ALLOC(st.pe_stats, N * 5);
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
-    TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
+    if (explicit_q) TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
 #ifdef GW_STAMPS
     TRY_ALLOC(st.stamps, st.n_slots * 16);
 #endif
@@ -301,7 +302,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
         HIP_TRY_D(hipMemcpy(d_ber2, b2.data(), b2.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY_D(hipMemcpy(d_cls2, c2.data(), c2.size(), hipMemcpyHostToDevice));
     }
-    HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
+    if (st.totals) HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
     if (st.bph) HIP_TRY_D(hipMemset(st.bph, 0, (size_t)N * GW_RING_PHYS * sizeof(GwBp)));
     rc = explicit_q ? gw_launch_init(st, nullptr) : gw_launch_init_sfx(st, nullptr);
@@ -380,6 +381,18 @@ int gw_stats_read(gw_env* env, gw_stats* out)
     if (rc) return rc;
     unsigned long long t[GW_T_COUNT] = {0};
     HIP_TRY(hipDeviceSynchronize());
+    if (env->st.sa) {                                 // suffix mode: sum the per-env counter records
+        const int64_t N = env->st.N;
+        std::vector<uint32_t> sa((size_t)N * 8);
+        HIP_TRY(hipMemcpy(sa.data(), env->st.sa, sa.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        memset(out, 0, sizeof *out);
+        for (int64_t e = 0; e < N; ++e) {
+            const uint32_t* r = &sa[(size_t)e * 8];
+            out->steps += r[0]; out->transmissions += r[1]; out->delivered += r[2]; out->appended += r[3];
+            out->popped += r[4]; out->dropped += r[5]; out->bad_actions += r[6]; out->flags_or |= r[7];
+        }
+        return GW_OK;
+    }
     std::vector<unsigned long long> slots((size_t)env->st.n_slots * GW_T_COUNT);
     HIP_TRY(hipMemcpy(slots.data(), env->st.totals, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int64_t w = 0; w < env->st.n_slots; ++w)
@@ -528,15 +541,18 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
     }
 #endif
     if (st.tk) {                                     // ---- suffix mode: packed records (ct_step_sfx.hip) ----
-        if (!strcmp(field, "flags")) { NEED(N, uint32_t); HIP_TRY(hipMemcpy(dst, st.flags, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
-        static const char* pes[5] = {"n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped"};
-        for (int k = 0; k < 5; ++k)
-            if (!strcmp(field, pes[k])) {
-                if (!st.pe_stats) return fail(GW_EFIELD, "field %s needs GW_CFG_PER_ENV_STATS", field);
-                NEED(N, uint64_t);
-                HIP_TRY(hipMemcpy(dst, st.pe_stats + (size_t)k * N, bytes, hipMemcpyDeviceToHost));
-                return GW_OK;
-            }
+        {
+            static const char* names[6] = {"n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped", "flags"};
+            static const int word[6] = {1, 2, 3, 4, 5, 7};
+            for (int k = 0; k < 6; ++k)
+                if (!strcmp(field, names[k])) {
+                    std::vector<uint32_t> sa((size_t)N * 8);
+                    HIP_TRY(hipMemcpy(sa.data(), st.sa, sa.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                    if (k == 5) { NEED(N, uint32_t); uint32_t* o = (uint32_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = sa[(size_t)e * 8 + 7]; }
+                    else { NEED(N, uint64_t); uint64_t* o = (uint64_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = sa[(size_t)e * 8 + word[k]]; }
+                    return GW_OK;
+                }
+        }
         const int RB = st.RB;
         std::vector<double> tw((size_t)N * 2);
         std::vector<uint32_t> tk((size_t)N * 4), ip((size_t)N * 4);

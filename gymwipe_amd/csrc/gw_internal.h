@@ -48,6 +48,8 @@ struct GwState {
     uint8_t*  qb;         // [N][RB]    bytes: queue length of sender 0..D-1, rx-power state of radio 0..D, pad
     GwBp*     bph;        // [N][GW_RING_PHYS]  ring of all breakpoints, entry j at [j & 127] (read only after >2 resets/100 ticks)
     int32_t   RB;         //            bytes per qb record: 16 * ceil((2*D + 1) / 16)
+    uint32_t* sa;         // [N][8]     per-env event counters {steps, tx, delivered, appended, popped, dropped,
+                          //            bad actions, sticky flags}: plain load/add/store with the rest of the state
     uint32_t* rvmask;     // [N]        bit i set <=> receivedValues[i] == payload_value
     int32_t*  last_abs;   // [N]        interpreter._lastAbsDifference
     uint8_t*  done;       // [N]        interpreter._done

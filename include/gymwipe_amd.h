@@ -89,7 +89,8 @@ typedef struct gw_config {
     int32_t max_duration;                   /* MAX_ASSIGN_DURATION 20 */
 } gw_config;
 
-#define GW_CFG_PER_ENV_STATS  1             /* keep per-env event counters (tests); costs HBM traffic */
+#define GW_CFG_PER_ENV_STATS  1             /* explicit-queue mode only: keep per-env event counters (the default
+                                               mode always keeps them, as 32-bit counters that wrap) */
 #define GW_CFG_EXPLICIT_QUEUE 2             /* MAC queues as explicit rings of packet sizes (generic, slower);
                                                default: exact suffix encoding of counter traffic, gw_queue.h */
 
@@ -134,7 +135,7 @@ int gw_received(gw_env* env, int32_t* out_dev, void* stream);
  *   "now" f64[N] | "wake" f64[N][D] | "counter" u32[N][D] | "qlen" i32[N][D]
  *   "queue" u32[N][D][GW_QUEUE_CAP] (logical order from the head, zero padded)
  *   "received" i32[N][D] | "latest_diff" i32[N] | "last_abs" i32[N] | "rx_power" f64[N][R]
- *   "flags" u32[N] | with GW_CFG_PER_ENV_STATS: "n_tx","n_delivered","n_appended","n_popped","n_dropped" u64[N] */
+ *   "flags" u32[N] | "n_tx","n_delivered","n_appended","n_popped","n_dropped" u64[N] (per-env event counts) */
 int gw_get_state(gw_env* env, const char* field, void* dst_host, size_t bytes);
 
 int gw_stats_read(gw_env* env, gw_stats* out);          /* synchronises the device */

@@ -13,7 +13,7 @@ env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 names = ["0 issue table+state loads, write LDS", "1 barrier", "2 state landed (touch ip)", "3 unpack, LDS lookups, consts",
          "4 announcement tx_times", "5 announcement decode, t_end", "6 window loop", "7 tail ticks_to(t_end)",
-         "8 other senders + pack", "9 qb store", "10 feedback + stores", "11 publish_totals"]
+         "8 other senders + pack", "9 qb store", "10 feedback + stores", "11 counters store"]
 rows = []
 env.reset()
 for k in range(48):

@@ -83,13 +83,14 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                                                          float* __restrict__ reward,
                                                          uint8_t* __restrict__ done)
 {
-    constexpr bool PACKED = (DT > 0 && DT <= 7);         // the whole byte record fits one uint4
+    constexpr bool PACKED = DT > 0;                      // the byte record is held in registers
+    constexpr int NWC = DT > 0 ? (2 * DT + 1 + 15) / 16 : 1;   // 16-byte words of the record
     const uint32_t N = (uint32_t)st.N;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     const int D = DT > 0 ? DT : c.D;
     const int R = D + 1, RRM = D;
     constexpr int S = GW_MAX_NSTATES;
-    const uint32_t RB = PACKED ? 16u : (uint32_t)st.RB;
+    const uint32_t RB = PACKED ? 16u * NWC : (uint32_t)st.RB;
 
     // ---- lookup tables -> LDS (a few hundred bytes for D = 4).  Their global loads are issued FIRST,
     //      the per-env state loads right behind them, and only then are the tables written to LDS,
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DM * S];
     const int n_tr = (R * R * S + 15) >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;   // 16-B chunks
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const bool one_pass = PACKED && nthr >= 64;          // D <= 7: every table fits one chunk per thread
+    const bool one_pass = DT > 0 && DT <= 7 && nthr >= 64;   // every table fits one chunk per thread
     uint4 r_tr = make_uint4(0u, 0u, 0u, 0u), r_be = r_tr, r_cl = r_tr;
     if (one_pass) {
         if (tid < n_tr) r_tr = ld<uint4>(st.trans, (uint32_t)tid << 4);
@@ -119,7 +120,11 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     const uint32_t o16 = e << 4;
     const uint32_t oq = e * RB;
     int d = 0, du = 0;
-    uint4 ip = make_uint4(0u, 0u, 0u, 0u), tk = ip, qw = ip, sa0 = ip, sa1 = ip;
+    uint4 ip = make_uint4(0u, 0u, 0u, 0u), tk = ip, sa0 = ip, sa1 = ip;
+    uint4 qw[NWC];
+#pragma unroll
+    for (int w = 0; w < NWC; ++w) qw[w] = ip;
+    uint32_t dyn_len = 0, dyn_sd = 0;                    // bytes of the record indexed by the action's device
     const uint32_t o32 = e << 5;
     double2 tw = make_double2(0.0, 0.0);
     if (live) {
@@ -128,7 +133,14 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         ip = ld<uint4>(st.ip, o16);
         tw = ld<double2>(st.tw, o16);
         tk = ld<uint4>(st.tk, o16);
-        if (PACKED) qw = ld<uint4>(st.qb, oq);
+        if (PACKED) {
+#pragma unroll
+            for (int w = 0; w < NWC; ++w) qw[w] = ld<uint4>(st.qb, oq + 16u * w);
+            if (NWC > 1 && (unsigned)d < (unsigned)DT) {  // dynamic index into a multi-word record: read the bytes directly
+                dyn_len = st.qb[oq + (uint32_t)d];
+                dyn_sd = st.qb[oq + (uint32_t)(DT + d)];
+            }
+        }
         sa0 = ld<uint4>(st.sa, o32);
         sa1 = ld<uint4>(st.sa, o32 + 16u);
     }
@@ -176,9 +188,14 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 
             uint32_t len_d, s_d_old, s_r_old;
             if (PACKED) {
-                len_d = byte_of(qw, (uint32_t)d);
-                s_d_old = byte_of(qw, (uint32_t)(DT + d));
-                s_r_old = byte_of(qw, (uint32_t)(2 * DT));
+                if (NWC == 1) {
+                    len_d = byte_of(qw[0], (uint32_t)d);
+                    s_d_old = byte_of(qw[0], (uint32_t)(DT + d));
+                } else {
+                    len_d = dyn_len;
+                    s_d_old = dyn_sd;
+                }
+                s_r_old = (word_of(qw[(2 * DT) >> 4], ((2 * DT) >> 2) & 3) >> (((2 * DT) & 3) * 8)) & 0xffu;
             } else {
                 len_d = st.qb[oq + (uint32_t)d];
                 s_d_old = st.qb[oq + (uint32_t)(D + d)];
@@ -310,26 +327,31 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 return s;
             };
             if (PACKED) {
-                uint32_t nb[16];
+                uint32_t nb[16 * NWC];
 #pragma unroll
-                for (int b = 0; b < 16; ++b) nb[b] = (word_of(qw, b >> 2) >> ((b & 3) * 8)) & 0xffu;
+                for (int b = 0; b < 16 * NWC; ++b) nb[b] = (word_of(qw[b >> 4], (b >> 2) & 3) >> ((b & 3) * 8)) & 0xffu;
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
                     Tally ki = {0, 0, 0, 0, 0};
                     const uint32_t li = gw_len_after_ticks(nb[i], n_ticks, (uint32_t)c.mult[i], ki);
-                    const uint32_t si = heard(i, nb[DT + i]);             // table lookups: loads, before any store
+                    const uint32_t si = heard(i, nb[DT + i]);             // LDS lookups
                     if (i != d) { k.app += ki.app; k.drop += ki.drop; }   // d's own ticks were counted in the window
                     nb[i] = (i == d) ? len_d : li;
                     nb[DT + i] = (i == d) ? s_d : si;
                 }
                 nb[2 * DT] = s_r;
-                uint4 o;
-                o.x = nb[0] | (nb[1] << 8) | (nb[2] << 16) | (nb[3] << 24);
-                o.y = nb[4] | (nb[5] << 8) | (nb[6] << 16) | (nb[7] << 24);
-                o.z = nb[8] | (nb[9] << 8) | (nb[10] << 16) | (nb[11] << 24);
-                o.w = nb[12] | (nb[13] << 8) | (nb[14] << 16) | (nb[15] << 24);
+                uint4 o[NWC];
+#pragma unroll
+                for (int w = 0; w < NWC; ++w) {
+                    const int b = 16 * w;
+                    o[w].x = nb[b + 0] | (nb[b + 1] << 8) | (nb[b + 2] << 16) | (nb[b + 3] << 24);
+                    o[w].y = nb[b + 4] | (nb[b + 5] << 8) | (nb[b + 6] << 16) | (nb[b + 7] << 24);
+                    o[w].z = nb[b + 8] | (nb[b + 9] << 8) | (nb[b + 10] << 16) | (nb[b + 11] << 24);
+                    o[w].w = nb[b + 12] | (nb[b + 13] << 8) | (nb[b + 14] << 16) | (nb[b + 15] << 24);
+                }
                 STAMP(9);
-                st_(st.qb, oq, o);
+#pragma unroll
+                for (int w = 0; w < NWC; ++w) st_(st.qb, oq + 16u * w, o[w]);
             } else {
                 for (int i = 0; i < D; ++i) {
                     if (i == d) continue;
@@ -450,6 +472,9 @@ int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* 
     case 3:  return launch<3>(st, cst, device, duration, obs, reward, done, stream);
     case 4:  return launch<4>(st, cst, device, duration, obs, reward, done, stream);
     case 6:  return launch<6>(st, cst, device, duration, obs, reward, done, stream);
+    case 8:  return launch<8>(st, cst, device, duration, obs, reward, done, stream);
+    case 16: return launch<16>(st, cst, device, duration, obs, reward, done, stream);
+    case 32: return launch<32>(st, cst, device, duration, obs, reward, done, stream);
     default: return launch<0>(st, cst, device, duration, obs, reward, done, stream);
     }
 }

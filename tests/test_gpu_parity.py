@@ -55,6 +55,15 @@ def test_parity_with_resets(D, N, K, explicit):
     _run(env, orc, dev, dur, reset_every=32)
 
 
+@pytest.mark.parametrize("D", [3, 5, 8, 32])
+def test_parity_other_device_counts(D):
+    """D = 3 (one-word record), 5 (generic in-memory path), 8 / 32 (multi-word records, max senders)."""
+    N, K = 512, 48
+    env, orc = _mk(N, D)
+    dev, dur = action_stream(200 + D, K, N, D)
+    _run(env, orc, dev, dur, reset_every=16, check_every=8)
+
+
 @pytest.mark.parametrize("explicit", QUEUE_MODES)
 def test_parity_fresh_env_no_reset(explicit):
     """The reference's own test never calls reset(): counters start at 1."""

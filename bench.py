@@ -36,6 +36,26 @@ def algorithmic_bytes(D, env_steps, appended, popped):
     return env_steps * (17 + 2 * (12 + 20 * D)) + 4 * (appended + popped)
 
 
+def state_bytes(D):
+    """Bytes the default kernel actually loads + stores per env-step."""
+    rb = 16 * ((2 * D + 1 + 15) // 16)
+    return (16 + 16 + 16 + rb + 32 + 8) + (16 + 4 + 8 + rb + 32 + 9)
+
+
+def measured_traffic(D, N):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 for the gfx950
+    wide-load under-count + WRITE_SIZE, both in KB), if a profile of this exact shape is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            for row in json.load(fh)["rows"]:
+                if row["devices"] == D and row["envs"] == N:
+                    return (2 * row["fetch_kb"] + row["write_kb"]) * 1024.0
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(D, seconds_target=12.0):
     """The oracle on the host cores, same action distribution, same reset cadence."""
     import numpy as np
@@ -98,10 +118,10 @@ def main():
 
     # outputs as three views of ONE packed record buffer so that the end-of-step observation
     # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
-    from gymwipe_amd.sharding import ObservationGather, StepRecord
+    from gymwipe_amd.sharding import PipelinedGather, StepRecord
+    pipe = PipelinedGather(N, dev_t, world) if (world > 1 and not args.no_gather) else None
     rec = StepRecord(N, dev_t)
     env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
-    gather = ObservationGather(rec, world) if (world > 1 and not args.no_gather) else None
 
     g = torch.Generator(device=dev_t)
     g.manual_seed(1234 + rank)
@@ -112,9 +132,12 @@ def main():
     def one(i):
         if i % RESET_EVERY == 0:
             env.reset()
+        if pipe is not None:                      # write this step's outputs into the free record
+            r = pipe.current()
+            env._obs, env._rew, env._done = r.obs, r.reward, r.done
         env.step(acts[i])
-        if gather is not None:
-            gather()
+        if pipe is not None:
+            pipe.submit()                         # async all-gather over RCCL; overlaps the next step
 
     for i in range(W):
         one(i)
@@ -131,6 +154,8 @@ def main():
     for i in range(W, W + K):
         one(i)
     ev[1].record()
+    if pipe is not None:
+        pipe.drain()                              # the job is done when the last gather has landed
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -169,11 +194,16 @@ def main():
                        "obs_gather": bool(world > 1 and not args.no_gather),
                        "launches_per_step": 1, "stream_ms_per_step": stream_s / K * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": measured_traffic(D, N),
                          "kernel": "ct_step_sfx_kernel", "kernel_avg_us": kern_avg_s * 1e6,
                          "how": "HIP events around the K timed launches on the launch stream / K (upper bound: includes gaps)",
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "algorithmic_bytes_per_env_step": bytes_launch / N},
+                         "algorithmic_bytes_per_env_step": bytes_launch / N,
+                         "state_bytes_per_env_step": state_bytes(D),
+                         "note": "achieved uses SURVEY 8d's algorithmic bytes (4 B per queue entry appended/popped); "
+                                 "the suffix queue encoding never materialises those entries, so measured HBM traffic "
+                                 "(traffic, rocprofv3 PMC, profiles/) is BELOW the algorithmic bytes and the kernel is "
+                                 "bound by f64 dependent-op latency at one wave per SIMD, not by HBM"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(D)

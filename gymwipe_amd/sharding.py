@@ -41,6 +41,39 @@ class StepRecord:
         return (flat[0:4 * n].view(torch.int32), flat[4 * n:8 * n].view(torch.float32), flat[8 * n:9 * n])
 
 
+class PipelinedGather:
+    """Double-buffered end-of-step gather: step k writes record k % 2 while the all-gather of step
+    k-1 is still in flight on the RCCL stream, so the exchange overlaps the next step's kernel."""
+
+    def __init__(self, num_envs, device, world_size=None, depth=2):
+        self.records = [StepRecord(num_envs, device) for _ in range(depth)]
+        self.gathers = [ObservationGather(r, world_size) for r in self.records]
+        self.pending = [None] * depth
+        self.depth = depth
+        self.k = 0
+
+    def current(self):
+        """The record the NEXT step must write; waits for the gather that last used it."""
+        i = self.k % self.depth
+        if self.pending[i] is not None:
+            self.pending[i].wait()
+            self.pending[i] = None
+        return self.records[i]
+
+    def submit(self):
+        """Start gathering the record just written."""
+        i = self.k % self.depth
+        self.pending[i] = self.gathers[i](async_op=True)
+        self.k += 1
+        return self.gathers[i]
+
+    def drain(self):
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
+
+
 class ObservationGather:
     """All-gather of equally sized StepRecords over the default process group."""
 
@@ -51,11 +84,14 @@ class ObservationGather:
         self.record = record
         self.out = torch.empty(self.world * record.nbytes, dtype=torch.uint8, device=record.buf.device)
 
-    def __call__(self):
-        """Gather every rank's record; returns the [world, nbytes] byte tensor (valid after the
-        collective completes on the current stream)."""
-        self._dist.all_gather_into_tensor(self.out, self.record.buf)
-        return self.out.view(self.world, self.record.nbytes)
+    def __call__(self, async_op=False):
+        """Gather every rank's record.  Synchronous form: returns the [world, nbytes] byte tensor
+        (valid once the collective has completed on the current stream).  With async_op=True the
+        collective runs on the backend's own stream and the Work handle is returned: the caller may
+        launch the next env.step() right away and must wait() on the handle before this record's
+        buffer (or `out`) is written again."""
+        work = self._dist.all_gather_into_tensor(self.out, self.record.buf, async_op=async_op)
+        return work if async_op else self.out.view(self.world, self.record.nbytes)
 
     def unpack(self):
         """(obs[W*N], reward[W*N], done[W*N]) of the whole job, rank-major (== global env order

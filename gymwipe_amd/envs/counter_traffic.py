@@ -174,17 +174,34 @@ class VecCounterTrafficEnv(BaseEnv):
                                        obs.data_ptr(), self._stream()))
         return obs
 
+    def _ready(self, t):
+        """int32, contiguous, right shape, on this env's GPU: usable in place."""
+        torch = _torch()
+        return (type(t) is torch.Tensor and t.dtype is torch.int32 and t.device == self.device
+                and t.dim() == 1 and t.shape[0] == self.num_envs and t.is_contiguous())
+
     def step(self, action):
         """One env.step() for all N envs: ``action = {"device": int32[N], "duration": int32[N]}``
         (torch tensors on the env's GPU are used in place).  Returns
         ``(obs int32[N], reward float32[N], done uint8[N], info)``; an action outside the action
         space flags its env (``check()`` raises) and leaves that env untouched."""
-        dev = self._as_i32(action["device"], "device")
-        dur = self._as_i32(action["duration"], "duration")
+        torch = _torch()
+        dev, dur = action["device"], action["duration"]
+        if not self._ready(dev):
+            dev = self._as_i32(dev, "device")
+        if not self._ready(dur):
+            dur = self._as_i32(dur, "duration")
         obs, rew, done = self._outputs()
-        with _torch().cuda.device(self.device):
-            nat.check(self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(),
-                                      rew.data_ptr(), done.data_ptr(), self._stream()))
+        idx = self.device.index or 0
+        if torch.cuda.current_device() == idx:                 # the one-process-per-GPU case: no context switch
+            rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                                 done.data_ptr(), torch._C._cuda_getCurrentRawStream(idx))
+        else:
+            with torch.cuda.device(self.device):
+                rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                                     done.data_ptr(), self._stream())
+        if rc:
+            nat.check(rc)
         self._last = (obs, rew, done)
         return obs, rew, done, self._info()
 

@@ -25,13 +25,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, total, D, K, seed, out_dir):
+def _worker(rank, world, port, total, D, K, seed, out_dir, pipelined=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gymwipe_amd.sharding import ObservationGather, StepRecord, shard_range
+        from gymwipe_amd.sharding import ObservationGather, PipelinedGather, StepRecord, shard_range
         from oracle.ct_oracle import CtOracle
         lo, hi = shard_range(total, world, rank)
         n = hi - lo
@@ -41,16 +41,25 @@ def _worker(rank, world, port, total, D, K, seed, out_dir):
         shard = CtOracle(n, D)
         rec = StepRecord(n, "cpu")
         gather = ObservationGather(rec, world)
+        pipe = PipelinedGather(n, "cpu", world) if pipelined else None
         shard.reset()
         got = []
         for k in range(K):
             o, r, d = shard.step(dev[k, lo:hi], dur[k, lo:hi])
-            rec.obs.copy_(torch.from_numpy(o))
-            rec.reward.copy_(torch.from_numpy(r))
-            rec.done.copy_(torch.from_numpy(d))
-            gather()
-            go, gr, gd = gather.unpack()
+            cur = pipe.current() if pipelined else rec       # waits for the gather that last used this buffer
+            cur.obs.copy_(torch.from_numpy(o))
+            cur.reward.copy_(torch.from_numpy(r))
+            cur.done.copy_(torch.from_numpy(d))
+            if pipelined:
+                g = pipe.submit()                            # asynchronous all-gather of the record just written
+                pipe.pending[(pipe.k - 1) % pipe.depth].wait()
+            else:
+                g = gather
+                g()
+            go, gr, gd = g.unpack()
             got.append((go.numpy().copy(), gr.numpy().copy(), gd.numpy().copy()))
+        if pipelined:
+            pipe.drain()
         if rank == 0:
             whole = CtOracle(total, D)
             whole.reset()
@@ -67,6 +76,14 @@ def test_two_rank_shard_and_gather(tmp_path):
     world, total, D, K = 2, 96, 4, 12
     port = _free_port()
     mp.spawn(_worker, args=(world, port, total, D, K, 31, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_two_rank_pipelined_gather(tmp_path):
+    """The double-buffered asynchronous gather bench.py uses at N > 1."""
+    world, total, D, K = 2, 64, 2, 9
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, D, K, 32, str(tmp_path), True), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 

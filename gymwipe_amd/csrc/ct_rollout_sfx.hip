@@ -1,0 +1,396 @@
+// ct_rollout_sfx.hip -- gw_rollout(): K consecutive env.step() calls from pre-staged actions in ONE
+// persistent launch, for the default (suffix) state layout.
+//
+// Why a second kernel: with one launch per step every wave lasts as long as its slowest env (0..9
+// data transmissions per step, 1.6 on average), so ~80% of the lane-iterations of the window loop are
+// idle.  Here a lane is not tied to the step boundary of its neighbours: the loop body is ONE
+// TRANSMISSION (the announcement of a step or a data packet, same arithmetic), and a lane that
+// finishes a step immediately starts its next one.  Over K steps the per-lane work evens out, the env
+// state stays in registers, and the only per-step memory traffic is 2 bytes of action in and 1 byte of
+// feedback out:
+//     pack kernel    actions int32[K][N] x2  ->  u16[N][K]  (device | duration << 8)
+//     rollout kernel state <-> registers once; feedback u8[N][K] = (diff+1) | (reward+10) << 2 | done << 7
+//     expand kernel  u8[N][K] -> obs int32[K][N], reward f32[K][N], done u8[K][N]
+// Results are bit-identical to K calls of the step kernel (tests compare both with the oracle).
+// The step semantics and reference citations are those of ct_step_sfx.hip / ct_common.hip.h.
+#include "ct_common.hip.h"
+#include "gw_queue.h"
+
+using namespace gwk;
+
+namespace {
+
+template <class T>
+__device__ __forceinline__ T ld(const void* base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_(void* base, uint32_t byte_off, const T& v)
+{
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ uint32_t word_of(const uint4& w, int i)
+{
+    return i == 0 ? w.x : (i == 1 ? w.y : (i == 2 ? w.z : w.w));
+}
+
+__device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls_valid, double ber, const TxTimes& x,
+                                       double br, double hdr_bits, double pay_bits, uint32_t& fl)
+{
+    if (!(x.t_e >= x.stop)) fl |= GW_FLAG_REFEXC;
+    if (cls_valid && cls != GW_CLS_COMPUTE) return cls == GW_CLS_OK;
+    uint32_t dummy = 0;
+    return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
+}
+
+// actions [K][N] int32 x 2  ->  [N][Kp] u16, Kp = K rounded up to 8 (one 16-byte load = 8 steps)
+__global__ void pack_actions_kernel(uint32_t N, int K, int Kp, const int32_t* __restrict__ device,
+                                    const int32_t* __restrict__ duration, uint16_t* __restrict__ packed)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    for (int k0 = 0; k0 < Kp; k0 += 8) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            uint32_t v = 0xffffu;                                    // beyond K: never consumed
+            if (k < K) {
+                const int32_t dv = device[(size_t)k * N + e], du = duration[(size_t)k * N + e];
+                // anything outside a byte is invalid for every configuration (D <= 32, max_duration checked below)
+                v = ((uint32_t)dv > 0xfeu || (uint32_t)du > 0xfeu) ? 0xffffu : ((uint32_t)dv | ((uint32_t)du << 8));
+            }
+            w[j >> 1] |= v << ((j & 1) * 16);
+        }
+        *reinterpret_cast<uint4*>(packed + (size_t)e * Kp + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// feedback u8[N][Kp] -> obs/reward/done [K][N]
+__global__ void expand_feedback_kernel(uint32_t N, int K, int Kp, int center, int pv, const uint8_t* __restrict__ fb,
+                                       int32_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    for (int k0 = 0; k0 < Kp; k0 += 16) {
+        const uint4 w = *reinterpret_cast<const uint4*>(fb + (size_t)e * Kp + k0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = k0 + j;
+            if (k < K) {
+                const uint32_t b = (word_of(w, j >> 2) >> ((j & 3) * 8)) & 0xffu;
+                obs[(size_t)k * N + e] = center + pv * ((int)(b & 3u) - 1);
+                reward[(size_t)k * N + e] = (float)((int)((b >> 2) & 31u) - 10);
+                done[(size_t)k * N + e] = (uint8_t)(b >> 7);
+            }
+        }
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevConst c, int K, int Kp,
+                                                            const uint16_t* __restrict__ actions,
+                                                            uint8_t* __restrict__ feedback)
+{
+    constexpr int NWC = (2 * DT + 1 + 15) / 16;
+    constexpr int S = GW_MAX_NSTATES;
+    constexpr int D = DT, R = DT + 1, RRM = DT;
+    const uint32_t N = (uint32_t)st.N;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+
+    // ---- lookup tables -> LDS ----------------------------------------------------------------------
+    constexpr int TRANS_B = (R * R * S + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_trans[TRANS_B];
+    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DT * S];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DT * S];
+    {
+        const int n_tr = TRANS_B >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;
+        for (int i = threadIdx.x; i < n_tr; i += blockDim.x) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)i << 4)) = ld<uint4>(st.trans, (uint32_t)i << 4);
+        for (int i = threadIdx.x; i < n_be; i += blockDim.x) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)i << 4)) = ld<uint4>(st.ber2, (uint32_t)i << 4);
+        for (int i = threadIdx.x; i < n_cl; i += blockDim.x) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)i << 4)) = ld<uint4>(st.cls2, (uint32_t)i << 4);
+    }
+    __syncthreads();
+    if (e >= N) return;
+
+    // ---- state -> registers --------------------------------------------------------------------------
+    const uint32_t o16 = e << 4, o32 = e << 5, oq = e * (16u * NWC);
+    const uint4 ip = ld<uint4>(st.ip, o16);
+    const double2 tw = ld<double2>(st.tw, o16);
+    const uint4 tk = ld<uint4>(st.tk, o16);
+    uint4 sa0 = ld<uint4>(st.sa, o32), sa1 = ld<uint4>(st.sa, o32 + 16u);
+    uint32_t len[DT], sta[R];
+    {
+        uint4 qw[NWC];
+#pragma unroll
+        for (int w = 0; w < NWC; ++w) qw[w] = ld<uint4>(st.qb, oq + 16u * w);
+#pragma unroll
+        for (int i = 0; i < DT; ++i) len[i] = (word_of(qw[i >> 4], (i >> 2) & 3) >> ((i & 3) * 8)) & 0xffu;
+#pragma unroll
+        for (int j = 0; j < R; ++j) sta[j] = (word_of(qw[(DT + j) >> 4], ((DT + j) >> 2) & 3) >> (((DT + j) & 3) * 8)) & 0xffu;
+    }
+    double now = tw.x, wake = tw.y;
+    uint32_t tau = tk.x;
+    const uint32_t nbp = tk.y;
+    GwBp bpc, bpp;
+    bpc.t0 = tk.z; bpc.c0 = tk.w;
+    bpp.t0 = ip.x; bpp.c0 = ip.y;
+    const GwBp* hist = st.bph + ((size_t)e << 7);
+    uint32_t rvm = ip.z;
+    int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
+    uint32_t dn = ip.w >> 31;
+
+    const StepMath m(c);
+    const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
+    const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
+    const int mh = c.mac_hdr, pv = c.payload_value;
+    uint32_t mult[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) mult[i] = (uint32_t)c.mult[i];
+
+    Tally kt = {0, 0, 0, 0, 0};
+    uint32_t k_steps = 0, k_bad = 0, fl = 0;
+
+    // ---- per-step variables of the lane's current step -------------------------------------------------
+    int k = 0;                      // step index
+    bool data_mode = false;         // false: the next transmission is the announcement of step k
+    int d = 0;                      // addressed sender of the current step
+    uint32_t len_d = 0, mult_d = 1, inv16_d = 65536u, tau_base = tau;   // lens[] are valid as of tau_base
+    uint32_t n_data = 0, s_r_run = 0;
+    double cur = now, stopw = 0.0, t_end = 0.0;
+    bool cls_valid = false;
+    uint32_t fbw = 0;               // feedback bytes of up to 4 steps, flushed as one dword
+
+    const uint16_t* act = actions + (size_t)e * Kp;
+    uint8_t* fbp = feedback + (size_t)e * Kp;
+    uint4 aw = ld<uint4>(act, 0);   // actions of steps 0..7
+
+    // all counter ticks with wake < t (or <= t), applied to the addressed sender's live queue length
+    auto ticks_to = [&](double t, bool inclusive) {
+        uint32_t kk = 0;
+        for (;;) {
+            const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
+            const bool b0 = inclusive ? (wake <= t) : (wake < t);
+            const bool b1 = inclusive ? (w1 <= t) : (w1 < t);
+            const bool b2 = inclusive ? (w2 <= t) : (w2 < t);
+            const bool b3 = inclusive ? (w3 <= t) : (w3 < t);
+            if (inclusive && (wake == t || w1 == t || w2 == t || w3 == t)) fl |= GW_FLAG_TIE;
+            kk += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;
+            wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
+            if (!b3) break;
+        }
+        tau += kk;
+        len_d = gw_len_after_ticks(len_d, kk, mult_d, kt);
+    };
+
+    // end of step k: remaining ticks, every other sender and radio, feedback byte (A.5, interpreter)
+    auto end_step = [&]() {
+        ticks_to(t_end, true);
+        const uint32_t n_ticks = tau - tau_base;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            Tally ki = {0, 0, 0, 0, 0};
+            const uint32_t li = gw_len_after_ticks(len[i], n_ticks, mult[i], ki);
+            uint32_t si = s_trans[(uint32_t)((i * R + RRM) * S) + sta[i]];            // heard the announcement
+            for (uint32_t n = 0; n < n_data; ++n) {                                    // ... and d's data
+                const uint32_t s2 = s_trans[(uint32_t)((i * R + d) * S) + si];
+                if (s2 == si) break;
+                si = s2;
+            }
+            if (i != d) { kt.app += ki.app; kt.drop += ki.drop; sta[i] = si; len[i] = li; }
+            else len[i] = len_d;
+        }
+        tau_base = tau;
+        sta[RRM] = s_r_run;
+        const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
+        const int32_t abs_d = latest < 0 ? -latest : latest;
+        int32_t r = last_abs - abs_d;
+        last_abs = abs_d;
+        r = r > 10 ? 10 : (r < -10 ? -10 : r);
+        const uint32_t byte = (uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | ((uint32_t)(r + 10) << 2) | (dn << 7);
+        fbw |= byte << ((k & 3) * 8);
+        if ((k & 3) == 3 || k == K - 1) { st_(fbp, (uint32_t)(k & ~3), fbw); fbw = 0; }
+        now = t_end;
+        k_steps++;
+        k++;
+        data_mode = false;
+        if ((k & 7) == 0 && k < K) aw = ld<uint4>(act, (uint32_t)k * 2u);                // next 8 actions
+    };
+
+    // ---- the lane's event loop: ONE transmission per iteration ------------------------------------------
+    while (k < K) {
+        int pay_bytes;
+        uint32_t cls_x, rx_sel;          // decode class of this transmission; 0 = announcement at d, 1 = data at RRM
+        double ber_x;
+        if (data_mode) {
+            // window loop of simple_stack.py:397-434 at sender d, up to the next SEND
+            bool have = true;
+            if (len_d == 0) {
+                if (wake < stopw) {
+                    cur = wake;
+                    wake = wake + interval;
+                    tau++;
+                    len_d = gw_len_after_ticks(0u, 1u, mult_d, kt);
+                } else have = false;
+            }
+            uint32_t s = 0;
+            if (have) {
+                const uint32_t age = gw_ceil_div(len_d, mult_d, inv16_d);
+                s = base_bytes + gw_tick_value(tau - age, bpc, bpp, nbp, hist, bound);
+                const double need = m.over_rate((double)(s * 8u));
+                if (!((stopw - cur) > need)) have = false;
+            }
+            if (!have) { end_step(); continue; }
+            len_d--;
+            kt.pop++;
+            pay_bytes = (int)s - mh;
+            rx_sel = 1u;
+        } else {
+            // start of step k: counter_traffic.py:146-158
+            const uint32_t a = (word_of(aw, (k & 7) >> 1) >> ((k & 1) * 16)) & 0xffffu;
+            d = (int)(a & 0xffu);
+            const int du = (int)(a >> 8);
+            if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
+                fl |= GW_FLAG_BADACT;                        // env untouched, feedback repeats the current values
+                k_bad++;
+                const uint32_t byte = (uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | (10u << 2) | (dn << 7);
+                fbw |= byte << ((k & 3) * 8);
+                if ((k & 3) == 3 || k == K - 1) { st_(fbp, (uint32_t)(k & ~3), fbw); fbw = 0; }
+                k++;
+                if ((k & 7) == 0 && k < K) aw = ld<uint4>(act, (uint32_t)k * 2u);
+                continue;
+            }
+            // bring every queue length to the current tick; select the addressed sender's
+            {
+                const uint32_t n_ticks = tau - tau_base;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) len[i] = gw_len_after_ticks(len[i], n_ticks, mult[i], kt);
+                tau_base = tau;
+            }
+            len_d = 0; mult_d = 1; inv16_d = 65536u;
+            uint32_t s_d_old = 0;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+                if (i == d) { len_d = len[i]; mult_d = mult[i]; inv16_d = c.inv16[i]; s_d_old = sta[i]; }
+            const int slots = du * c.duration_factor;
+            const int L = ndigits(slots);
+            pay_bytes = L;
+            cur = now;
+            cls_valid = now < c.cls_limit;
+            // noise state of d after hearing the RRM; the RRM's running state during this step
+            const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];
+#pragma unroll
+            for (int i = 0; i < DT; ++i) if (i == d) sta[i] = s_d;
+            s_r_run = sta[RRM];
+            n_data = 0;
+            rx_sel = 0u;
+            stopw = (double)slots * slot;                    // turned into an absolute time once t_r is known
+            t_end = (double)(slots + 1) * slot;
+        }
+
+        // ---- the transmission itself -----------------------------------------------------------------------
+        uint32_t s_rx;
+        if (rx_sel) {
+            s_rx = s_trans[(uint32_t)((RRM * R + d) * S) + s_r_run];   // the RRM hears sender d (again)
+            s_r_run = s_rx;
+            ber_x = s_ber[(uint32_t)((D + d) * S) + s_rx];
+            cls_x = s_cls[(uint32_t)((D + d) * S) + s_rx];
+        } else {
+            uint32_t s_d_now = 0;
+#pragma unroll
+            for (int i = 0; i < DT; ++i) if (i == d) s_d_now = sta[i];
+            ber_x = s_ber[(uint32_t)(d * S) + s_d_now];
+            cls_x = s_cls[(uint32_t)(d * S) + s_d_now];
+        }
+        const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay_bytes * 8)));
+        kt.tx++;
+        const bool ok = decode(m, cls_x, cls_valid, ber_x, x, br, hdr_bits, (double)(pay_bytes * 8) * c.coded_factor, fl);
+
+        if (rx_sel) {
+            n_data++;
+            if (ok) {
+                kt.deliv++;
+                rvm |= (1u << d);
+                if (pv == c.counter_bound) dn = 1u;
+            }
+            if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
+            ticks_to(x.t_e, true);
+            cur = x.t_e;
+            if (!(cur < stopw)) end_step();
+        } else {
+            const double t_r = x.t_e;
+            stopw = t_r + stopw;                             // simple_stack.py:401
+            t_end = t_r + t_end;                             // simple_stack.py:557-558
+            cur = t_r;
+            if (ok) {
+                ticks_to(cur, false);                        // ties at the window start: the MAC runs first
+                data_mode = true;
+            } else {
+                end_step();
+            }
+        }
+    }
+
+    // ---- registers -> state --------------------------------------------------------------------------------
+    {
+        uint32_t nb[16 * NWC];
+#pragma unroll
+        for (int b = 0; b < 16 * NWC; ++b) nb[b] = 0u;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) nb[i] = len[i];
+#pragma unroll
+        for (int j = 0; j < R; ++j) nb[DT + j] = sta[j];
+#pragma unroll
+        for (int w = 0; w < NWC; ++w) {
+            const int b = 16 * w;
+            uint4 o;
+            o.x = nb[b + 0] | (nb[b + 1] << 8) | (nb[b + 2] << 16) | (nb[b + 3] << 24);
+            o.y = nb[b + 4] | (nb[b + 5] << 8) | (nb[b + 6] << 16) | (nb[b + 7] << 24);
+            o.z = nb[b + 8] | (nb[b + 9] << 8) | (nb[b + 10] << 16) | (nb[b + 11] << 24);
+            o.w = nb[b + 12] | (nb[b + 13] << 8) | (nb[b + 14] << 16) | (nb[b + 15] << 24);
+            st_(st.qb, oq + 16u * w, o);
+        }
+    }
+    st_(st.tw, o16, make_double2(now, wake));
+    st_(st.tk, o16, tau);
+    st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
+    sa0.x += k_steps; sa0.y += kt.tx; sa0.z += kt.deliv; sa0.w += kt.app;
+    sa1.x += kt.pop;  sa1.y += kt.drop; sa1.z += k_bad;  sa1.w |= fl;
+    st_(st.sa, o32, sa0);
+    st_(st.sa, o32 + 16u, sa1);
+}
+
+template <int DT>
+int launch_rollout(const GwState& st, const GwDevConst& cst, int K, int Kp, const uint16_t* act, uint8_t* fb, void* stream)
+{
+    const unsigned blk = 64;
+    const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
+    hipLaunchKernelGGL((ct_rollout_sfx_kernel<DT>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
+} // namespace
+
+// Returns GW_EUNSUPPORTED when this (D, K) has no fused kernel: the caller falls back to K step launches.
+int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const int32_t* device, const int32_t* duration,
+                          int32_t* obs, float* reward, uint8_t* done, uint16_t* act_buf, uint8_t* fb_buf, int k_cap, void* stream)
+{
+    const int Kp = (K + 15) / 16 * 16;
+    if (K <= 0 || Kp > k_cap || cst.max_duration > 0xfe) return GW_EUNSUPPORTED;
+    const uint32_t N = (uint32_t)st.N;
+    const unsigned g256 = (unsigned)((st.N + 255) / 256);
+    hipLaunchKernelGGL(pack_actions_kernel, dim3(g256), dim3(256), 0, (hipStream_t)stream, N, K, Kp, device, duration, act_buf);
+    int rc;
+    switch (st.D) {
+    case 2:  rc = launch_rollout<2>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
+    case 3:  rc = launch_rollout<3>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
+    case 4:  rc = launch_rollout<4>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
+    case 8:  rc = launch_rollout<8>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
+    case 16: rc = launch_rollout<16>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
+    default: return GW_EUNSUPPORTED;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(expand_feedback_kernel, dim3(g256), dim3(256), 0, (hipStream_t)stream, N, K, Kp, cst.counter_bound,
+                       cst.payload_value, fb_buf, obs, reward, done);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}

@@ -269,6 +269,13 @@ int gw_create(const gw_config* cfg, gw_env** out)
         TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);     TRY_ALLOC(st.ip, N * 4);
         TRY_ALLOC(st.qb, N * st.RB);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
         TRY_ALLOC(st.sa, N * 8);
+        {
+            const char* rc_env = getenv("GW_ROLLOUT_CAP");      // steps per fused rollout launch
+            int cap = rc_env ? atoi(rc_env) : 64;
+            if (cap < 0) cap = 0;
+            st.rcap = (cap + 15) / 16 * 16;
+            if (st.rcap > 0) { TRY_ALLOC(st.ract, N * st.rcap);  TRY_ALLOC(st.rfb, N * st.rcap); }
+        }
     }
     if (explicit_q) TRY_ALLOC(st.flags, N);
     if (explicit_q && (cfg->flags & GW_CFG_PER_ENV_STATS)) TRY_ALLOC(st.pe_stats, N * 5);
@@ -356,7 +363,18 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
     int rc = select_device(env);
     if (rc) return rc;
     const int64_t N = env->st.N;
-    for (int32_t s = 0; s < steps; ++s) {
+    int32_t s = 0;
+    // fused persistent rollout (ct_rollout_sfx.hip) in chunks of up to rcap steps, when this D has one
+    while (env->st.tk && env->st.rcap > 0 && s < steps) {
+        const int32_t chunk = steps - s < env->st.rcap ? steps - s : env->st.rcap;
+        const int64_t o = (int64_t)s * N;
+        rc = gw_launch_rollout_sfx(env->st, env->cst_host, chunk, device_dev + o, duration_dev + o, obs_dev + o,
+                                   reward_dev + o, done_dev + o, env->st.ract, env->st.rfb, env->st.rcap, stream);
+        if (rc == GW_EUNSUPPORTED) break;
+        if (rc) return fail(GW_EHIP, "rollout kernel launch failed at step %d", s);
+        s += chunk;
+    }
+    for (; s < steps; ++s) {                                   // generic path: one step launch per step
         const int64_t o = (int64_t)s * N;
         if (launch_step(env, device_dev + o, duration_dev + o, obs_dev + o, reward_dev + o, done_dev + o, stream))
             return fail(GW_EHIP, "step kernel launch failed at step %d", s);

@@ -48,6 +48,9 @@ struct GwState {
     uint8_t*  qb;         // [N][RB]    bytes: queue length of sender 0..D-1, rx-power state of radio 0..D, pad
     GwBp*     bph;        // [N][GW_RING_PHYS]  ring of all breakpoints, entry j at [j & 127] (read only after >2 resets/100 ticks)
     int32_t   RB;         //            bytes per qb record: 16 * ceil((2*D + 1) / 16)
+    uint16_t* ract;       // [N][rcap]  rollout scratch: packed actions (device | duration << 8)
+    uint8_t*  rfb;        // [N][rcap]  rollout scratch: packed feedback bytes
+    int32_t   rcap;       //            steps per fused rollout launch (multiple of 16)
     uint32_t* sa;         // [N][8]     per-env event counters {steps, tx, delivered, appended, popped, dropped,
                           //            bad actions, sticky flags}: plain load/add/store with the rest of the state
     uint32_t* rvmask;     // [N]        bit i set <=> receivedValues[i] == payload_value
@@ -103,6 +106,8 @@ int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* 
                        int32_t* obs, float* reward, uint8_t* done, void* stream);
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
 int gw_launch_init_sfx(const GwState& st, void* stream);
+int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const int32_t* device, const int32_t* duration,
+                          int32_t* obs, float* reward, uint8_t* done, uint16_t* act_buf, uint8_t* fb_buf, int k_cap, void* stream);
 int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream);
 
 #define GW_MAX_MULT        15          // packets per tick supported by the suffix encoding's ceil-div

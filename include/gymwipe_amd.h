@@ -124,7 +124,9 @@ int gw_reset(gw_env* env, const uint8_t* mask_dev, int32_t* obs_dev, void* strea
 int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
             int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 
-/* K consecutive env.step() calls, one kernel launch each, inputs/outputs laid out [K][N]. */
+/* K consecutive env.step() calls from pre-staged actions, inputs/outputs laid out [K][N].  In the default
+ * mode this is ONE persistent launch per 64 steps (state in registers, lanes free-running through their
+ * own event sequences: ct_rollout_sfx.hip); results are identical to K gw_step calls. */
 int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int32_t* duration_dev,
                int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 

@@ -157,3 +157,49 @@ def test_invalid_action_is_flagged_and_env_left_untouched():
         one.step({"device": 2, "duration": 1})
     with pytest.raises(AssertionError):
         one.step({"device": 0, "duration": 20})
+
+
+@pytest.mark.parametrize("D,N,K", [(2, 2048, 64), (4, 2048, 37), (4, 1024, 150), (16, 512, 48), (5, 256, 20)])
+def test_fused_rollout_matches_oracle(D, N, K):
+    """gw_rollout: one persistent launch per <= 64 steps (free-running lanes, state in registers)
+    must give exactly what K env.step() calls give -- outputs of every step and the final state.
+    (D = 5 has no fused kernel and takes the per-step fallback inside gw_rollout.)"""
+    import torch
+    env, orc = _mk(N, D)
+    dev, dur = action_stream(300 + D + K, K, N, D)
+    assert (env.reset().cpu().numpy() == orc.reset()).all()
+    obs, rew, done = env.rollout(torch.from_numpy(dev), torch.from_numpy(dur))
+    obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    for k in range(K):
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (obs[k] == oo).all(), "obs differ at step %d" % k
+        assert (rew[k] == orr).all(), "reward differs at step %d" % k
+        assert (done[k] == od).all()
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
+    env.check()
+    # and a per-step call afterwards continues from the same state
+    dev2, dur2 = action_stream(9, 3, N, D)
+    for k in range(3):
+        o, r, d_, _ = env.step({"device": torch.from_numpy(dev2[k]), "duration": torch.from_numpy(dur2[k])})
+        oo, orr, od = orc.step(dev2[k], dur2[k])
+        assert (o.cpu().numpy() == oo).all() and (r.cpu().numpy() == orr).all()
+    assert_state_equal(env, orc, STATE_FIELDS, where="after rollout + steps")
+
+
+def test_fused_rollout_with_invalid_actions():
+    import torch
+    from gymwipe_amd import _native as nat
+    env, orc = _mk(256, 4)
+    dev, dur = action_stream(41, 20, 256, 4)
+    env.reset(); orc.reset()
+    bad = dev.copy(); bad_du = dur.copy()
+    bad[7, 3] = 4; bad_du[11, 200] = 25; bad[0, 17] = -1
+    obs, rew, done = env.rollout(torch.from_numpy(bad), torch.from_numpy(bad_du))
+    assert env.stats()["bad_actions"] == 3
+    fl = env.get_state("flags")
+    assert all(fl[i] & nat.FLAG_BADACT for i in (3, 200, 17)) and not fl[0] & nat.FLAG_BADACT
+    # untouched envs behave exactly like the oracle
+    ok = np.ones(256, bool); ok[[3, 200, 17]] = False
+    for k in range(20):
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (obs[k].cpu().numpy()[ok] == oo[ok]).all() and (rew[k].cpu().numpy()[ok] == orr[ok]).all()

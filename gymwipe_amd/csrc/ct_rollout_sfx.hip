@@ -152,10 +152,19 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     uint32_t k_steps = 0, k_bad = 0, fl = 0;
 
     // ---- per-step variables of the lane's current step -------------------------------------------------
+    // Laziness that keeps the loop body small (all exact):
+    //   * queue lengths: len[i] is valid as of tick tb[i]; a sender is brought up to date when it is
+    //     addressed (and everyone once at the end): k ticks are min(len + k*mult, 100) in one go;
+    //   * counter ticks between the end of a window and the end of the step are not counted at the
+    //     step end but by the next step's first count (tick counting is cumulative in time).
     int k = 0;                      // step index
     bool data_mode = false;         // false: the next transmission is the announcement of step k
+    bool finish = false;            // the current step is over: close it at the top of the next iteration
     int d = 0;                      // addressed sender of the current step
-    uint32_t len_d = 0, mult_d = 1, inv16_d = 65536u, tau_base = tau;   // lens[] are valid as of tau_base
+    uint32_t len_d = 0, mult_d = 0, inv16_d = 65536u;
+    uint32_t tb[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) tb[i] = tau;
     uint32_t n_data = 0, s_r_run = 0;
     double cur = now, stopw = 0.0, t_end = 0.0;
     bool cls_valid = false;
@@ -165,65 +174,18 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     uint8_t* fbp = feedback + (size_t)e * Kp;
     uint4 aw = ld<uint4>(act, 0);   // actions of steps 0..7
 
-    // all counter ticks with wake < t (or <= t), applied to the addressed sender's live queue length
-    auto ticks_to = [&](double t, bool inclusive) {
-        uint32_t kk = 0;
-        for (;;) {
-            const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
-            const bool b0 = inclusive ? (wake <= t) : (wake < t);
-            const bool b1 = inclusive ? (w1 <= t) : (w1 < t);
-            const bool b2 = inclusive ? (w2 <= t) : (w2 < t);
-            const bool b3 = inclusive ? (w3 <= t) : (w3 < t);
-            if (inclusive && (wake == t || w1 == t || w2 == t || w3 == t)) fl |= GW_FLAG_TIE;
-            kk += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;
-            wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
-            if (!b3) break;
-        }
-        tau += kk;
-        len_d = gw_len_after_ticks(len_d, kk, mult_d, kt);
-    };
-
-    // end of step k: remaining ticks, every other sender and radio, feedback byte (A.5, interpreter)
-    auto end_step = [&]() {
-        ticks_to(t_end, true);
-        const uint32_t n_ticks = tau - tau_base;
-#pragma unroll
-        for (int i = 0; i < DT; ++i) {
-            Tally ki = {0, 0, 0, 0, 0};
-            const uint32_t li = gw_len_after_ticks(len[i], n_ticks, mult[i], ki);
-            uint32_t si = s_trans[(uint32_t)((i * R + RRM) * S) + sta[i]];            // heard the announcement
-            for (uint32_t n = 0; n < n_data; ++n) {                                    // ... and d's data
-                const uint32_t s2 = s_trans[(uint32_t)((i * R + d) * S) + si];
-                if (s2 == si) break;
-                si = s2;
-            }
-            if (i != d) { kt.app += ki.app; kt.drop += ki.drop; sta[i] = si; len[i] = li; }
-            else len[i] = len_d;
-        }
-        tau_base = tau;
-        sta[RRM] = s_r_run;
-        const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
-        const int32_t abs_d = latest < 0 ? -latest : latest;
-        int32_t r = last_abs - abs_d;
-        last_abs = abs_d;
-        r = r > 10 ? 10 : (r < -10 ? -10 : r);
-        const uint32_t byte = (uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | ((uint32_t)(r + 10) << 2) | (dn << 7);
+    auto put_feedback = [&](uint32_t byte) {
         fbw |= byte << ((k & 3) * 8);
         if ((k & 3) == 3 || k == K - 1) { st_(fbp, (uint32_t)(k & ~3), fbw); fbw = 0; }
-        now = t_end;
-        k_steps++;
         k++;
-        data_mode = false;
         if ((k & 7) == 0 && k < K) aw = ld<uint4>(act, (uint32_t)k * 2u);                // next 8 actions
     };
 
-    // ---- the lane's event loop: ONE transmission per iteration ------------------------------------------
+    // ---- the lane's event loop: at most ONE transmission per iteration, every block appears once ----------
     while (k < K) {
-        int pay_bytes;
-        uint32_t cls_x, rx_sel;          // decode class of this transmission; 0 = announcement at d, 1 = data at RRM
-        double ber_x;
-        if (data_mode) {
-            // window loop of simple_stack.py:397-434 at sender d, up to the next SEND
+        // (1) data mode: is there a packet that still fits the window?  (simple_stack.py:397-434)
+        uint32_t s = 0;
+        if (data_mode && !finish) {
             bool have = true;
             if (len_d == 0) {
                 if (wake < stopw) {
@@ -233,68 +195,87 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
                     len_d = gw_len_after_ticks(0u, 1u, mult_d, kt);
                 } else have = false;
             }
-            uint32_t s = 0;
             if (have) {
                 const uint32_t age = gw_ceil_div(len_d, mult_d, inv16_d);
                 s = base_bytes + gw_tick_value(tau - age, bpc, bpp, nbp, hist, bound);
                 const double need = m.over_rate((double)(s * 8u));
                 if (!((stopw - cur) > need)) have = false;
             }
-            if (!have) { end_step(); continue; }
-            len_d--;
-            kt.pop++;
-            pay_bytes = (int)s - mh;
-            rx_sel = 1u;
-        } else {
-            // start of step k: counter_traffic.py:146-158
+            if (!have) finish = true;
+        }
+
+        // (2) close the step (A.5 + interpreter feedback); the other senders' queues stay lazy
+        if (finish) {
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                if (i == d) { len[i] = len_d; tb[i] = tau; }
+                else {
+                    uint32_t si = s_trans[(uint32_t)((i * R + RRM) * S) + sta[i]];      // heard the announcement
+                    for (uint32_t n = 0; n < n_data; ++n) {                              // ... and d's data
+                        const uint32_t s2 = s_trans[(uint32_t)((i * R + d) * S) + si];
+                        if (s2 == si) break;
+                        si = s2;
+                    }
+                    sta[i] = si;
+                }
+            }
+            sta[RRM] = s_r_run;
+            const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
+            const int32_t abs_d = latest < 0 ? -latest : latest;
+            int32_t r = last_abs - abs_d;
+            last_abs = abs_d;
+            r = r > 10 ? 10 : (r < -10 ? -10 : r);
+            now = t_end;
+            k_steps++;
+            finish = false;
+            data_mode = false;
+            mult_d = 0;                              // no addressed sender between steps
+            put_feedback((uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | ((uint32_t)(r + 10) << 2) | (dn << 7));
+            if (k >= K) break;
+        }
+
+        // (3) start of step k (counter_traffic.py:146-158): set up the announcement
+        int pay_bytes;
+        bool is_data = data_mode;
+        if (!data_mode) {
             const uint32_t a = (word_of(aw, (k & 7) >> 1) >> ((k & 1) * 16)) & 0xffffu;
             d = (int)(a & 0xffu);
             const int du = (int)(a >> 8);
             if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
-                fl |= GW_FLAG_BADACT;                        // env untouched, feedback repeats the current values
+                fl |= GW_FLAG_BADACT;                // env untouched, feedback repeats the current values
                 k_bad++;
-                const uint32_t byte = (uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | (10u << 2) | (dn << 7);
-                fbw |= byte << ((k & 3) * 8);
-                if ((k & 3) == 3 || k == K - 1) { st_(fbp, (uint32_t)(k & ~3), fbw); fbw = 0; }
-                k++;
-                if ((k & 7) == 0 && k < K) aw = ld<uint4>(act, (uint32_t)k * 2u);
+                put_feedback((uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | (10u << 2) | (dn << 7));
                 continue;
             }
-            // bring every queue length to the current tick; select the addressed sender's
-            {
-                const uint32_t n_ticks = tau - tau_base;
-#pragma unroll
-                for (int i = 0; i < DT; ++i) len[i] = gw_len_after_ticks(len[i], n_ticks, mult[i], kt);
-                tau_base = tau;
-            }
-            len_d = 0; mult_d = 1; inv16_d = 65536u;
-            uint32_t s_d_old = 0;
+            uint32_t l0 = 0, t0 = 0, s_d_old = 0;
 #pragma unroll
             for (int i = 0; i < DT; ++i)
-                if (i == d) { len_d = len[i]; mult_d = mult[i]; inv16_d = c.inv16[i]; s_d_old = sta[i]; }
+                if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = c.inv16[i]; s_d_old = sta[i]; }
+            len_d = gw_len_after_ticks(l0, tau - t0, mult_d, kt);          // the addressed queue, up to date
             const int slots = du * c.duration_factor;
-            const int L = ndigits(slots);
-            pay_bytes = L;
+            pay_bytes = ndigits(slots);
             cur = now;
             cls_valid = now < c.cls_limit;
-            // noise state of d after hearing the RRM; the RRM's running state during this step
-            const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];
+            const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];   // d after hearing the RRM
 #pragma unroll
             for (int i = 0; i < DT; ++i) if (i == d) sta[i] = s_d;
             s_r_run = sta[RRM];
             n_data = 0;
-            rx_sel = 0u;
-            stopw = (double)slots * slot;                    // turned into an absolute time once t_r is known
+            stopw = (double)slots * slot;            // become absolute times once t_r is known
             t_end = (double)(slots + 1) * slot;
+        } else {
+            len_d--;                                 // simple_stack.py:425
+            kt.pop++;
+            pay_bytes = (int)s - mh;
         }
 
-        // ---- the transmission itself -----------------------------------------------------------------------
-        uint32_t s_rx;
-        if (rx_sel) {
-            s_rx = s_trans[(uint32_t)((RRM * R + d) * S) + s_r_run];   // the RRM hears sender d (again)
-            s_r_run = s_rx;
-            ber_x = s_ber[(uint32_t)((D + d) * S) + s_rx];
-            cls_x = s_cls[(uint32_t)((D + d) * S) + s_rx];
+        // (4) the transmission: slot alignment, durations, decode at the receiver
+        uint32_t cls_x;
+        double ber_x;
+        if (is_data) {
+            s_r_run = s_trans[(uint32_t)((RRM * R + d) * S) + s_r_run];     // the RRM hears sender d (again)
+            ber_x = s_ber[(uint32_t)((D + d) * S) + s_r_run];
+            cls_x = s_cls[(uint32_t)((D + d) * S) + s_r_run];
         } else {
             uint32_t s_d_now = 0;
 #pragma unroll
@@ -306,29 +287,53 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
         kt.tx++;
         const bool ok = decode(m, cls_x, cls_valid, ber_x, x, br, hdr_bits, (double)(pay_bytes * 8) * c.coded_factor, fl);
 
-        if (rx_sel) {
+        // (5) consequences + the counter ticks up to the new current time (one instance of the counting loop)
+        bool incl;
+        if (is_data) {
             n_data++;
-            if (ok) {
+            if (ok) {                                // devices.py:163-168, counter_traffic.py:75-80
                 kt.deliv++;
                 rvm |= (1u << d);
                 if (pv == c.counter_bound) dn = 1u;
             }
             if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
-            ticks_to(x.t_e, true);
             cur = x.t_e;
-            if (!(cur < stopw)) end_step();
+            incl = true;                             // ticks are older events than the MAC's resume
+            if (!(cur < stopw)) finish = true;       // window timeout already processed
         } else {
             const double t_r = x.t_e;
-            stopw = t_r + stopw;                             // simple_stack.py:401
-            t_end = t_r + t_end;                             // simple_stack.py:557-558
+            stopw = t_r + stopw;                     // simple_stack.py:401
+            t_end = t_r + t_end;                     // simple_stack.py:557-558
             cur = t_r;
-            if (ok) {
-                ticks_to(cur, false);                        // ties at the window start: the MAC runs first
-                data_mode = true;
-            } else {
-                end_step();
-            }
+            incl = false;                            // ties at the window start: the MAC runs first
+            data_mode = true;
+            if (!ok) finish = true;                  // announcement not decoded: no window
         }
+        {
+            uint32_t kk = 0;
+            for (;;) {
+                const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
+                const bool b0 = incl ? (wake <= cur) : (wake < cur);
+                const bool b1 = incl ? (w1 <= cur) : (w1 < cur);
+                const bool b2 = incl ? (w2 <= cur) : (w2 < cur);
+                const bool b3 = incl ? (w3 <= cur) : (w3 < cur);
+                if (incl && (wake == cur || w1 == cur || w2 == cur || w3 == cur)) fl |= GW_FLAG_TIE;
+                kk += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;
+                wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
+                if (!b3) break;
+            }
+            tau += kk;
+            len_d = gw_len_after_ticks(len_d, kk, mult_d, kt);
+        }
+    }
+
+    // ---- catch up: ticks up to the end of the last step, every queue to the final tick ----------------------
+    {
+        uint32_t kk = 0;
+        while (wake <= now) { if (wake == now) fl |= GW_FLAG_TIE; wake = wake + interval; kk++; }
+        tau += kk;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) len[i] = gw_len_after_ticks(len[i], tau - tb[i], mult[i], kt);
     }
 
     // ---- registers -> state --------------------------------------------------------------------------------

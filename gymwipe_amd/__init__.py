@@ -10,6 +10,7 @@ keeps the reference's ``gym.Env`` / ``Interpreter`` surface.  There is no CPU
 fallback: without the HIP library or a GPU the envs raise.
 """
 from . import spaces                                   # noqa: F401
+from .plants import VecLinearPlant                       # noqa: F401
 from .envs import (CounterTrafficEnv, VecCounterTrafficEnv, Interpreter,   # noqa: F401
                    make, register, registry)
 

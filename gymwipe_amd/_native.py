@@ -26,6 +26,8 @@ EXPORTS = (
     "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_get_state",
     "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue",
     "gw_selftest_fastmath",
+    "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
+    "gw_plant_state_ptr", "gw_plant_get_state", "gw_now_ptr",
 )
 
 
@@ -54,6 +56,19 @@ class Config(C.Structure):
         ("net_header_bytes", C.c_int32),
         ("duration_factor", C.c_int32),
         ("max_duration", C.c_int32),
+    ]
+
+
+class PlantConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("hip_device", C.c_int32),
+        ("num_envs", C.c_int64),
+        ("A", C.c_double * 16),
+        ("B", C.c_double * 4),
+        ("dt", C.c_double),
+        ("x0", C.c_double * 4),
+        ("u0", C.c_double),
     ]
 
 
@@ -121,6 +136,14 @@ def lib():
     L.gw_selftest_queue.argtypes, L.gw_selftest_queue.restype = [C.c_uint64, i32, i32, i32], C.c_int
     L.gw_selftest_fastmath.argtypes = [C.POINTER(Config), C.POINTER(i32)]
     L.gw_selftest_fastmath.restype = C.c_int
+    L.gw_plant_config_default.argtypes, L.gw_plant_config_default.restype = [C.POINTER(PlantConfig), i64], C.c_int
+    L.gw_plant_create.argtypes, L.gw_plant_create.restype = [C.POINTER(PlantConfig), C.POINTER(vp)], C.c_int
+    L.gw_plant_destroy.argtypes, L.gw_plant_destroy.restype = [vp], C.c_int
+    L.gw_plant_update.argtypes, L.gw_plant_update.restype = [vp, vp, i64, vp], C.c_int
+    L.gw_plant_set_input.argtypes, L.gw_plant_set_input.restype = [vp, vp, vp, vp], C.c_int
+    L.gw_plant_state_ptr.argtypes, L.gw_plant_state_ptr.restype = [vp, C.POINTER(vp)], C.c_int
+    L.gw_plant_get_state.argtypes, L.gw_plant_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
+    L.gw_now_ptr.argtypes, L.gw_now_ptr.restype = [vp, C.POINTER(vp), C.POINTER(i64)], C.c_int
     if L.gw_abi_version() != ABI_VERSION:
         raise ImportError("gymwipe_amd: ABI mismatch (library %d, python %d); rebuild"
                           % (L.gw_abi_version(), ABI_VERSION))

@@ -30,6 +30,20 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+} // namespace
+
+// shared with gw_plant_api.cpp
+int gw_set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \
@@ -421,6 +435,14 @@ int gw_stats_read(gw_env* env, gw_stats* out)
     out->steps = t[GW_T_STEPS]; out->transmissions = t[GW_T_TX]; out->delivered = t[GW_T_DELIV];
     out->appended = t[GW_T_APP]; out->popped = t[GW_T_POP]; out->dropped = t[GW_T_DROP];
     out->flags_or = t[GW_T_FLAGS]; out->bad_actions = t[GW_T_BAD];
+    return GW_OK;
+}
+
+int gw_now_ptr(gw_env* env, const void** now_dev, int64_t* stride_bytes)
+{
+    if (!env || !now_dev || !stride_bytes) return fail(GW_EINVAL, "env/now/stride is NULL");
+    if (env->st.tw) { *now_dev = env->st.tw; *stride_bytes = 16; }          // {now, next tick} records
+    else { *now_dev = env->st.now; *stride_bytes = 8; }
     return GW_OK;
 }
 

@@ -78,6 +78,18 @@ enum { GW_CLS_COMPUTE = 0, GW_CLS_OK = 1, GW_CLS_HDR_FAIL = 2, GW_CLS_PAY_FAIL =
 
 enum { GW_T_STEPS = 0, GW_T_TX, GW_T_DELIV, GW_T_APP, GW_T_POP, GW_T_DROP, GW_T_FLAGS, GW_T_BAD, GW_T_COUNT };
 
+// Linear plant (plant_mfma.hip, gw_plant_api.cpp)
+struct GwPlantDev {
+    int64_t N;
+    double* x;                    // [N][4]
+    double* u;                    // [N]
+    double* t_last;               // [N]
+    unsigned long long* nsub;     // [N] substeps applied so far
+    const double* Pop;            // [KMAX/4][64]  A operand of the state MFMA, by lane
+    const double* Qop;            // [KMAX/4][64]  A operand of the input MFMA, by lane
+    double dt, inv_dt;
+};
+
 // Host-side link tables (gw_tables.cpp)
 struct GwHostTables {
     int D, R;

@@ -1,0 +1,104 @@
+// plant_mfma.hip -- batched linear plant  x <- A^n x + (sum_{j<n} A^j B) u  on the f64 matrix cores.
+//
+// Replaces OdePlant.updateState (gymwipe/plants/core.py:38-49: "step the plant by the simulated time
+// that passed since the last update") for the builder-defined linear plant of BASELINE config 4.
+//
+// Mapping onto v_mfma_f64_16x16x4_f64 (D[16x16] = A[16x4] * B[4x16] + C):
+//   K = 4   the state dimension,
+//   N = 16  environments per instruction,
+//   M = 16  FOUR candidate substep counts k0..k0+3 times 4 state components: row 4c+g of the A
+//           operand is row g of A^(k0+c).
+// Lane l = (g = l>>4, col = l&15) holds component g of env col as the B operand, and after the
+// instruction holds component g of all four candidates in its four result registers
+// (row = g + 4*reg).  So the result of one application is already where the next application needs
+// it, and choosing the candidate that matches the env's substep count is a per-lane register select.
+// The input term is a second MFMA on the same accumulator: A-operand column 0 = sum_{j<k} A^j B,
+// B-operand row 0 = u.  Envs needing more than GW_PLANT_KMAX substeps go round the loop again.
+#include <hip/hip_runtime.h>
+#include "gw_internal.h"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+
+namespace {
+
+__global__ __launch_bounds__(64) void plant_update_kernel(GwPlantDev p, const char* __restrict__ now_base, int64_t stride)
+{
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, col = lane & 15;
+    const int64_t tiles = (p.N + 15) >> 4;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t e = tile * 16 + col;
+        const bool live = e < p.N;
+        double xg = 0.0, u = 0.0, now = 0.0, tl = 0.0;
+        if (live) {
+            xg = p.x[e * 4 + g];
+            u = p.u[e];
+            tl = p.t_last[e];
+            now = *reinterpret_cast<const double*>(now_base + e * stride);
+        }
+        // substeps to take: n = round((now - last) / dt), nothing if time did not advance
+        long long n = 0;
+        if (live && now > tl) n = llrint((now - tl) * p.inv_dt);
+        const long long n_total = n;
+        const double ug = (g == 0) ? u : 0.0;                       // B operand of the input MFMA: row 0 = u
+        while (__any(n > 0)) {
+            const int chunk = n > GW_PLANT_KMAX ? GW_PLANT_KMAX : (int)n;   // this round's substeps (0 = done)
+            double xn = xg;
+            for (int grp = 0; grp < GW_PLANT_KMAX / 4 && __any(chunk > 4 * grp); ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
+                const double a_p = p.Pop[grp * 64 + lane];
+                const double a_q = p.Qop[grp * 64 + lane];
+                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_q, ug, acc, 0, 0, 0);
+                const int r = chunk - (4 * grp + 1);                 // which candidate is mine (if any)
+                if (r >= 0 && r < 4) xn = r == 0 ? acc.x : (r == 1 ? acc.y : (r == 2 ? acc.z : acc.w));
+            }
+            xg = xn;
+            n -= chunk;
+        }
+        if (live && n_total > 0) {
+            p.x[e * 4 + g] = xg;
+            if (g == 0) { p.t_last[e] = now; p.nsub[e] += (unsigned long long)n_total; }
+        }
+    }
+}
+
+__global__ void plant_set_input_kernel(GwPlantDev p, const double* __restrict__ u, const uint8_t* __restrict__ mask)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < p.N && (!mask || mask[e])) p.u[e] = u[e];
+}
+
+__global__ void plant_init_kernel(GwPlantDev p, double x0, double x1, double x2, double x3, double u0)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.N) return;
+    p.x[e * 4 + 0] = x0; p.x[e * 4 + 1] = x1; p.x[e * 4 + 2] = x2; p.x[e * 4 + 3] = x3;
+    p.u[e] = u0;
+    p.t_last[e] = 0.0;
+    p.nsub[e] = 0ull;
+}
+
+} // namespace
+
+int gw_plant_launch_update(const GwPlantDev& p, const void* now_base, int64_t stride, void* stream)
+{
+    const int64_t tiles = (p.N + 15) >> 4;
+    const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);   // >> 256 CUs; grid-stride over the rest
+    hipLaunchKernelGGL(plant_update_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, p, (const char*)now_base, stride);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
+int gw_plant_launch_set_input(const GwPlantDev& p, const double* u, const uint8_t* mask, void* stream)
+{
+    hipLaunchKernelGGL(plant_set_input_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, u, mask);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
+int gw_plant_launch_init(const GwPlantDev& p, const double* x0, double u0, void* stream)
+{
+    hipLaunchKernelGGL(plant_init_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p,
+                       x0[0], x0[1], x0[2], x0[3], u0);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}

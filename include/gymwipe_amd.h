@@ -148,6 +148,49 @@ int gw_state_bytes(gw_env* env, uint64_t* bytes);       /* HBM held by this hand
 int gw_link_info(gw_env* env, int32_t from, int32_t to, double* attenuation_db, double* rx_power_mw);
 int gw_noise_states(gw_env* env, int32_t radio, int32_t* count, double* values_mw /* [16] */);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Linear plant (BASELINE config 4): the plant side of the pendulum env.
+ *   replaces  OdePlant.updateState -- "advance the plant to the current simulated time, lazily"
+ *             (gymwipe/plants/core.py:38-49) and the SlidingPendulum getters / setMotorVelocity
+ *             (gymwipe/plants/sliding_pendulum.py:57-85)
+ * with a fixed-dt linear model  x <- A x + B u  (4 states, 1 input), n = round((now - last)/dt) substeps
+ * per call, evaluated on the f64 matrix cores (v_mfma_f64_16x16x4_f64).  BUILDER-DEFINED: the
+ * reference's plant is an ODE rigid-body world (py3ode, absent) inside an env that cannot be
+ * constructed (simtools.py:39-42), so there is nothing to pin parity to; the oracle is this library's
+ * own scalar restatement of the same recurrence (test tree), tolerance 1e-5 relative.
+ * ------------------------------------------------------------------------------------------------- */
+#define GW_PLANT_DIM   4
+#define GW_PLANT_KMAX  32                   /* substeps applied per matrix-core pass */
+
+typedef struct gw_plant_config {
+    int32_t abi_version;                    /* GW_ABI_VERSION */
+    int32_t hip_device;
+    int64_t num_envs;
+    double  A[GW_PLANT_DIM * GW_PLANT_DIM]; /* row-major one-substep state matrix */
+    double  B[GW_PLANT_DIM];                /* one-substep input vector */
+    double  dt;                             /* substep length, s */
+    double  x0[GW_PLANT_DIM];               /* initial state {wagon pos, wagon vel, angle, angle rate} */
+    double  u0;                             /* initial input (motor velocity; reference: 0.1) */
+} gw_plant_config;
+
+typedef struct gw_plant gw_plant;
+
+/* pendulum-like default: velocity-servoed wagon, small-angle pendulum, forward-Euler at dt = 1 ms */
+int gw_plant_config_default(gw_plant_config* cfg, int64_t num_envs);
+int gw_plant_create(const gw_plant_config* cfg, gw_plant** out);
+int gw_plant_destroy(gw_plant* p);
+/* advance env e to time *(double*)((char*)now_dev + e*stride_bytes); no-op where that is not later than its last update */
+int gw_plant_update(gw_plant* p, const void* now_dev, int64_t stride_bytes, void* stream);
+/* u[e] <- u_dev[e] where mask_dev is NULL or mask_dev[e] != 0 (setMotorVelocity; the caller updates first) */
+int gw_plant_set_input(gw_plant* p, const double* u_dev, const uint8_t* mask_dev, void* stream);
+/* device pointer to the state, double[N][4] (row e = {pos, vel, angle, rate}); valid until gw_plant_destroy */
+int gw_plant_state_ptr(gw_plant* p, double** x_dev);
+/* host copies for tests: "x" f64[N][4] | "u" f64[N] | "t_last" f64[N] | "substeps" u64[N] */
+int gw_plant_get_state(gw_plant* p, const char* field, void* dst_host, size_t bytes);
+
+/* device pointer + stride of the per-env simulated time of a gw_env (default mode), for gw_plant_update */
+int gw_now_ptr(gw_env* env, const void** now_dev, int64_t* stride_bytes);
+
 /* Host-only self-test hook (no GPU needed): fuzzes the MAC-queue encoding the default kernel uses
  * against an explicit deque(maxlen=100).  Returns the number of mismatches (0 = identical). */
 int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);

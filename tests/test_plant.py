@@ -1,0 +1,87 @@
+"""
+Linear plant (BASELINE config 4): the f64 matrix-core kernel against its scalar
+oracle.  Builder-defined model, PARITY UNPINNED against the reference (its plant is an ODE world in
+an env that cannot be constructed); tolerance 1e-5 relative as the north star states for
+floating-point plant state -- the observed difference is ~1e-13 (A^n precomputed vs n applications).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_plant_oracle_matches_numpy_recurrence():
+    from gymwipe_amd import _native as nat
+    from oracle.plant_oracle import PlantOracle
+    cfg = nat.PlantConfig()
+    nat.check(nat.lib().gw_plant_config_default(C.byref(cfg), 8))
+    A = np.array(list(cfg.A)).reshape(4, 4)
+    B = np.array(list(cfg.B))
+    assert cfg.dt == 1e-3 and cfg.u0 == 0.1                       # sliding_pendulum.py:52, inverted_pendulum.py:81
+    orc = PlantOracle(8, A, B, cfg.dt, list(cfg.x0), cfg.u0)
+    now = np.array([0.0, 0.001, 0.0029, 0.01, 0.0204, 0.05, 0.1, 1.0])
+    orc.update(now)
+    assert orc.substeps.tolist() == [0, 1, 3, 10, 20, 50, 100, 1000]
+    for e in range(8):
+        x = np.array(list(cfg.x0))
+        for _ in range(int(orc.substeps[e])):
+            x = A @ x + B * cfg.u0
+        assert np.allclose(orc.x[e], x, rtol=1e-12, atol=1e-15)
+    assert (np.abs(orc.x) < 10).all()                              # the default model is stable
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 37, 4096])
+def test_plant_kernel_matches_oracle(N):
+    import torch
+    import gymwipe_amd
+    from oracle.plant_oracle import PlantOracle
+    plant = gymwipe_amd.VecLinearPlant(N)
+    cfg = plant.config
+    orc = PlantOracle(N, list(cfg.A), list(cfg.B), cfg.dt, list(cfg.x0), cfg.u0)
+    rng = np.random.default_rng(5)
+    now = np.zeros(N)
+    worst = 0.0
+    for it in range(30):
+        # steps of 0 .. 45 ms (more than GW_PLANT_KMAX = 32 substeps in one call) and some envs standing still
+        now = now + rng.integers(0, 46, N) * 1e-3 * (rng.random(N) > 0.1) + rng.random(N) * 2e-4
+        plant.updateState(torch.from_numpy(now))
+        orc.update(now)
+        if it % 7 == 3:
+            u = rng.normal(0, 0.3, N)
+            mask = rng.random(N) > 0.5
+            plant.setMotorVelocity(torch.from_numpy(u), torch.from_numpy(mask))
+            orc.set_input(u, mask)
+        x = plant.state()
+        assert (plant.get_state("substeps") == orc.substeps).all()
+        assert (plant.get_state("t_last") == orc.t_last).all()
+        scale = np.maximum(np.abs(orc.x), 1e-6)
+        err = np.abs(x - orc.x) / scale
+        worst = max(worst, float(err.max()))
+        assert err.max() < 1e-5, "relative error %g at iteration %d" % (err.max(), it)
+    assert worst < 1e-9                                            # in practice ~1e-13
+    assert plant.getAngle().shape == (N,) and plant.getWagonPos().shape == (N,)
+
+
+@pytest.mark.gpu
+def test_plant_follows_the_env_clock():
+    """The pendulum-env coupling: step the band-assignment env, then advance every plant to its
+    env's simulated time (read in place through gw_now_ptr)."""
+    import torch
+    import gymwipe_amd
+    from gymwipe_amd import _native as nat
+    N = 512
+    env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=2)
+    plant = gymwipe_amd.VecLinearPlant(N)
+    base, stride = C.c_void_p(), C.c_int64()
+    nat.check(env._L.gw_now_ptr(env._h, C.byref(base), C.byref(stride)))
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    env.reset()
+    for _ in range(10):
+        env.step({"device": torch.randint(0, 2, (N,), dtype=torch.int32, device="cuda", generator=g),
+                  "duration": torch.randint(0, 20, (N,), dtype=torch.int32, device="cuda", generator=g)})
+        plant.updateState((base.value, stride.value))
+    now = env.get_state("now")
+    assert (plant.get_state("t_last") == now).all()
+    sub = plant.get_state("substeps").astype(np.int64)
+    assert (np.abs(sub - now / 1e-3) <= 10).all()                  # one rounding per update, 10 updates

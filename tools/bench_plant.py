@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 (builder-defined): 32 768 envs, each env.step() = band-assignment step (2 devices)
++ linear-plant advance to the env's new simulated time on the f64 matrix cores.  Prints one JSON line."""
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gymwipe_amd
+from gymwipe_amd import _native as nat
+
+N, K, W = int(os.environ.get("N", 32768)), 256, 32
+env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=2)
+plant = gymwipe_amd.VecLinearPlant(N)
+base, stride = C.c_void_p(), C.c_int64()
+nat.check(env._L.gw_now_ptr(env._h, C.byref(base), C.byref(stride)))
+now = (base.value, stride.value)
+g = torch.Generator(device="cuda"); g.manual_seed(7)
+dev = torch.randint(0, 2, (W + K, N), dtype=torch.int32, device="cuda", generator=g)
+dur = torch.randint(0, 20, (W + K, N), dtype=torch.int32, device="cuda", generator=g)
+acts = [{"device": dev[i], "duration": dur[i]} for i in range(W + K)]
+env.reset()
+for i in range(W):
+    env.step(acts[i]); plant.updateState(now)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for i in range(W, W + K):
+    if i % 64 == 0:
+        env.reset()
+    env.step(acts[i]); plant.updateState(now)
+e1.record(); torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+sub = int(plant.get_state("substeps").sum())
+# useful flops: 40 per plant substep (2*4*4 + 2*4); issued MFMA flops: 2 MFMAs x 2*16*16*4 per 16 envs per candidate group
+print(json.dumps({"workload": "pendulum band-assign env (builder-defined): %d envs, CounterTraffic D=2 step + linear plant advance" % N,
+                  "env_steps_per_s": N * K / wall, "ms_per_step": wall / K * 1e3, "stream_ms_per_step": e0.elapsed_time(e1) / K,
+                  "plant_substeps_total": sub, "useful_plant_gflops": 40.0 * sub / (W + K) * K / wall / 1e9}))

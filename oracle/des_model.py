@@ -1044,3 +1044,74 @@ def scenario_notifier_admission():
     sim.run(1); out.append(snap())
     sim.run(25); out.append(snap())
     return out
+
+
+# --------------------------------------------------------------------------
+# The reference's benchmark scenario (tests/test_benchmark.py:20-91), restated:
+# a grid of PHY-only devices that each send one 39-byte packet every 10 ms at
+# 40 dBm from a random phase, uncoordinated -- the one place the reference
+# exercises concurrent transmissions (a non-trivial interference sum).
+# --------------------------------------------------------------------------
+GRID_SEND_INTERVAL = 1e-2            # tests/test_benchmark.py:17
+GRID_MOVE_INTERVAL = 1e-3            # :18
+GRID_TX_POWER_DBM = 40.0             # :47
+GRID_MESSAGE = "A message to all my homies"     # :44 (26 bytes)
+
+
+def grid_positions(n):
+    """tests/test_benchmark.py:64-68: cols = int(sqrt(n)); device i at (i / cols, i % cols)."""
+    cols = int(sqrt(n)) if n > 0 else 1
+    return [(i / cols, float(i % cols)) for i in range(n)]
+
+
+class GridDevice(Device):
+    """SendingDevice (tests/test_benchmark.py:20-50): a PHY and a sender process, no MAC."""
+
+    def __init__(self, world, index, x, y, send_interval, initial_delay):
+        Device.__init__(self, world.sim, "Device%d" % index, x, y)
+        self.index = index
+        self.phy = Phy(world.sim, self, world.band)
+        self.mcs = BpskMcs()
+        self.n_sent = 0
+        sim = world.sim
+
+        def sender():
+            yield sim.timeout(initial_delay)
+            while True:
+                yield sim.timeout(send_interval)
+                packet = Pkt(MacHeader(bytes([0] * 5 + [index % 255]), bytes([255] * 6), 0), Blob(GRID_MESSAGE))
+                cmd = Cmd(sim, "SEND", packet=packet, power=GRID_TX_POWER_DBM, mcs=self.mcs)
+                self.n_sent += 1
+                self.phy.mac_in.trigger(cmd)
+        sim.process(sender())
+
+
+def scenario_grid(n, initial_delays, sim_time, moves=None, positions=None):
+    """Run the grid for `sim_time` seconds.  `initial_delays[i]` replaces random.uniform(0, SEND_INTERVAL)
+    (tests/test_benchmark.py:67); `moves` (optional) is a list of (time, device, x, y) position updates
+    standing in for the mover processes (:73-85).  Returns per-device counters and final state."""
+    w = World()
+    pos = positions or grid_positions(n)
+    devs = [GridDevice(w, i, pos[i][0], pos[i][1], GRID_SEND_INTERVAL, initial_delays[i]) for i in range(n)]
+    if moves:
+        def mover():
+            last = 0.0
+            for (t, i, x, y) in moves:
+                if t > last:
+                    yield w.sim.timeout(t - last)
+                    last = t
+                devs[i].position.set(x, y)
+        w.sim.process(mover())
+    if n:
+        w.sim.run(sim_time)
+    out = {"n_sent": [d.n_sent for d in devs], "n_tx": len(w.band.log),
+           "tx_start": [t.start for t in w.band.log], "tx_sender": [t.sender.index for t in w.band.log],
+           "hdr_ok": [], "hdr_fail": [], "pay_ok": [], "pay_fail": [], "rx_power": [d.phy.rx_power for d in devs],
+           "now": w.sim.now, "events": w.sim.n_popped}
+    for d in devs:
+        dec = d.phy.decisions
+        out["hdr_ok"].append(sum(1 for k in dec if k[0] == "hdr" and k[1]))
+        out["hdr_fail"].append(sum(1 for k in dec if k[0] == "hdr" and not k[1]))
+        out["pay_ok"].append(sum(1 for k in dec if k[0] == "pay" and k[1]))
+        out["pay_fail"].append(sum(1 for k in dec if k[0] == "pay" and not k[1]))
+    return out

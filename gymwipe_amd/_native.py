@@ -28,6 +28,7 @@ EXPORTS = (
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
     "gw_plant_state_ptr", "gw_plant_get_state", "gw_now_ptr",
+    "gw_grid_config_default", "gw_grid_create", "gw_grid_destroy", "gw_grid_run", "gw_grid_get_state",
 )
 
 
@@ -69,6 +70,21 @@ class PlantConfig(C.Structure):
         ("dt", C.c_double),
         ("x0", C.c_double * 4),
         ("u0", C.c_double),
+    ]
+
+
+GRID_MAX_DEVICES = 64
+
+
+class GridConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("hip_device", C.c_int32), ("num_envs", C.c_int64),
+        ("num_devices", C.c_int32), ("reserved", C.c_int32),
+        ("pos", (C.c_double * 2) * GRID_MAX_DEVICES),
+        ("slot", C.c_double), ("frequency", C.c_double), ("bandwidth", C.c_double), ("temperature_c", C.c_double),
+        ("bit_rate", C.c_double), ("code_rate", C.c_double), ("max_ber", C.c_double),
+        ("tx_power_dbm", C.c_double), ("send_interval", C.c_double),
+        ("header_bytes", C.c_int32), ("payload_bytes", C.c_int32),
     ]
 
 
@@ -144,6 +160,11 @@ def lib():
     L.gw_plant_state_ptr.argtypes, L.gw_plant_state_ptr.restype = [vp, C.POINTER(vp)], C.c_int
     L.gw_plant_get_state.argtypes, L.gw_plant_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     L.gw_now_ptr.argtypes, L.gw_now_ptr.restype = [vp, C.POINTER(vp), C.POINTER(i64)], C.c_int
+    L.gw_grid_config_default.argtypes, L.gw_grid_config_default.restype = [C.POINTER(GridConfig), i64, i32], C.c_int
+    L.gw_grid_create.argtypes, L.gw_grid_create.restype = [C.POINTER(GridConfig), vp, C.POINTER(vp)], C.c_int
+    L.gw_grid_destroy.argtypes, L.gw_grid_destroy.restype = [vp], C.c_int
+    L.gw_grid_run.argtypes, L.gw_grid_run.restype = [vp, C.c_double, vp], C.c_int
+    L.gw_grid_get_state.argtypes, L.gw_grid_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     if L.gw_abi_version() != ABI_VERSION:
         raise ImportError("gymwipe_amd: ABI mismatch (library %d, python %d); rebuild"
                           % (L.gw_abi_version(), ABI_VERSION))

@@ -1,0 +1,343 @@
+// grid_phy.hip -- N replicas of the reference's PHY grid benchmark (tests/test_benchmark.py:20-91),
+// the workload with concurrent transmissions and a real all-pairs interference sum.
+//
+// One wave per replica, one lane per radio.  Every lane keeps ITS device's pending events
+// (at most one of each kind) in registers; the next event of the replica is the wave-wide minimum over
+// (time, priority, insertion id) -- SimPy's heap order -- found with a shuffle butterfly.  The event's
+// handler then runs with all lanes in parallel wherever the model loops over radios:
+//     NOTIFY  (a transmission starts)  every other radio adds its received power  simple_stack.py:130-144
+//     END     (it completes)           ... and subtracts it again                 :146-157
+//     power change while receiving     count bit errors, re-evaluate the BER      :161-188,:223-231
+// Insertion ids are handed out in the order the reference creates its events (lane order inside a
+// loop over radios, via ballot + popcount), which is what decides who transmits first when several
+// radios leave "wait until my reception ends" (:199-200) in the same instant -- the common case here.
+//
+// Events (one slot per kind and device), priority URGENT(0) before NORMAL(1) at equal times:
+//   TICK   sender process wakes: SEND command to the PHY, next tick in 10 ms   tests/test_benchmark.py:33-48
+//   HINIT  PHY handler starts (URGENT): wait for reception end or for the slot  simple_stack.py:192-204
+//   RXFIN  the reception this handler waited for has ended                      :200, :267
+//   SLOT   slot boundary: create the transmission                               physical.py:576-608
+//   NOTIFY zero-delay "new transmission" notification                           physical.py:601-607
+//   RXINIT a radio's receive process starts (URGENT)                            simple_stack.py:214-221
+//   HDR    header end: receivers decide the header                              :238-248
+//   END    transmission end: sender resumes, powers drop, payload decisions     :209-212, :146-157, :251-267
+//   RXPROC / HPROC  a receive / handler process object completes (admission flags, queued commands)
+//                                                                               simtools.py:322-392
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "gw_internal.h"
+
+namespace {
+
+enum { EV_TICK = 0, EV_HINIT, EV_SLOT, EV_RXFIN, EV_HDR, EV_END, EV_NOTIFY, EV_RXINIT, EV_RXPROC, EV_HPROC, EV_COUNT };
+constexpr uint32_t kNormal = 0x80000000u;       // key = priority bit | insertion id
+constexpr double kInf = __builtin_inf();
+
+// physical.py:25-58,82-98,208-212 with the device libm
+__device__ __forceinline__ double ber_bpsk(double sig_mw, double noise_mw, double ten_log_br, double sqrt2pi)
+{
+    const double s = 10 * log10(sig_mw);
+    const double n = 10 * log10(noise_mw);
+    if (s <= n) return 0.5;
+    const double ratio_db = s - n - ten_log_br;
+    const double ratio = pow(10.0, ratio_db / 10);
+    const double x = sqrt(2 * ratio);
+    const double e = 2.718281828459045;
+    return (1 - pow(e, -1.4 * x)) * pow(e, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
+}
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
+{
+    return __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double seconds)
+{
+    const int lane = threadIdx.x;
+    const int n = g.n;
+    const int64_t env = blockIdx.x;
+    const bool me = lane < n;                            // this lane is a radio
+
+    // ---- static link table -> LDS: prx[from][to] (mW) -------------------------------------------------
+    extern __shared__ double s_prx[];
+    for (int i = lane; i < n * n; i += 64) s_prx[i] = g.prx[i];
+    __syncthreads();
+
+    // ---- state -> registers -----------------------------------------------------------------------------
+    GwGridLane L;
+    if (me) L = g.lanes[env * n + lane];
+    else {
+        for (int k = 0; k < EV_COUNT; ++k) { L.ev_t[k] = kInf; L.ev_k[k] = 0xffffffffu; }
+        L.rx_power = 0; L.flags = 0;
+    }
+    GwGridEnv E = g.envs[env];                           // wave-uniform: now, eid, counters
+    double now = E.now;
+    uint32_t eid = E.eid;
+    uint32_t n_events = E.events, n_tx = E.n_tx;
+    // SimMan.runSimulation(seconds): an URGENT stop event at now + seconds, created now (simtools.py:85-88)
+    const double t_stop = now + seconds;
+    const double t_stop_at = now + (t_stop - now);
+    uint32_t k_stop;                                     // URGENT: priority bit clear
+    if (E.first_run) { k_stop = (uint32_t)n; eid = (uint32_t)(2 * n + 1); E.first_run = 0; }   // see grid_init_kernel
+    else k_stop = eid++;
+
+    const double slot = g.slot, interval = g.send_interval, br = g.bit_rate;
+    const double hdr_bits = g.hdr_bits, pay_bits = g.pay_bits, hd = g.hdr_dur, pd = g.pay_dur;
+
+    auto push = [&](int kind, double t, uint32_t key) { L.ev_t[kind] = t; L.ev_k[kind] = key; };
+    // power change at a radio that is receiving: count errors from the (never advanced) segment start,
+    // then re-evaluate the BER unless the received transmission is over (simple_stack.py:223-231)
+    auto power_changed = [&]() {
+        L.err_sum += L.ber * (now - L.t_seg) * br;
+        if (!(now >= L.rx_stop)) {
+            const double sig = s_prx[L.rx_src * n + lane];
+            const double noise = L.rx_power - sig;
+            if (!(noise >= 0)) L.flags |= GW_FLAG_REFEXC;            // the reference asserts here
+            L.ber = ber_bpsk(sig, noise, g.ten_log_br, g.sqrt2pi);
+        }
+    };
+
+    for (;;) {
+        // ---- pop: minimum over (time, key) of every lane's pending events ---------------------------------
+        double bt = kInf; uint32_t bk = 0xffffffffu; int bkind = 0;
+#pragma unroll
+        for (int k = 0; k < EV_COUNT; ++k) {
+            const bool better = L.ev_t[k] < bt || (L.ev_t[k] == bt && L.ev_k[k] < bk);
+            if (better) { bt = L.ev_t[k]; bk = L.ev_k[k]; bkind = k; }
+        }
+        int bwho = lane;
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ot = __shfl_xor(bt, off, 64);
+            const uint32_t ok = __shfl_xor(bk, off, 64);
+            const int okind = __shfl_xor(bkind, off, 64);
+            const int owho = __shfl_xor(bwho, off, 64);
+            if (ot < bt || (ot == bt && ok < bk)) { bt = ot; bk = ok; bkind = okind; bwho = owho; }
+        }
+        // the stop event: URGENT, created at the start of this run
+        if (!(bt < t_stop_at || (bt == t_stop_at && bk < k_stop))) { now = t_stop_at; break; }
+        now = bt;
+        n_events++;
+        if (n_events - E.events > g.max_events) { if (me) L.flags |= GW_FLAG_CARRY; break; }   // every wave reaches this: no hang
+        const int dev = bwho;                             // wave-uniform
+        const bool mine = me && lane == dev;
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < EV_COUNT; ++k) if (k == bkind) { L.ev_t[k] = kInf; L.ev_k[k] = 0xffffffffu; }
+        }
+
+        switch (bkind) {
+        case EV_TICK: {
+            int inc = 0;
+            if (mine) {
+                if (L.started) {                          // tests/test_benchmark.py:36-48
+                    L.n_sent++;
+                    if (L.handler_running) L.queued++;
+                    else { L.handler_running = 1; push(EV_HINIT, now, eid); inc = 1; }   // URGENT
+                }
+                L.started = 1;
+                push(EV_TICK, now + interval, kNormal | (eid + inc));
+                inc += 1;
+            }
+            eid += __shfl(inc, dev, 64);
+            break;
+        }
+        case EV_HINIT: {
+            int inc = 0;
+            if (mine) {
+                if (L.receiving) L.waiting_rx = 1;        // yield nReceivingFinished.event: nothing is scheduled
+                else { L.transmitting = 1; push(EV_SLOT, now + (slot - fmod(now, slot)), kNormal | eid); inc = 1; }
+            }
+            eid += __shfl(inc, dev, 64);
+            break;
+        }
+        case EV_RXFIN: {
+            if (mine) { L.transmitting = 1; push(EV_SLOT, now + (slot - fmod(now, slot)), kNormal | eid); }
+            eid += 1;
+            break;
+        }
+        case EV_SLOT: {                                   // FrequencyBand.transmit + Transmission.__init__
+            if (mine) {
+                const double dur = hd + pd;
+                L.tx_stop = now + dur;
+                const double th = now + hd;
+                push(EV_HDR, th > now ? now + (th - now) : now + 0.0, kNormal | eid);
+                push(EV_END, L.tx_stop > now ? now + (L.tx_stop - now) : now + 0.0, kNormal | (eid + 1));
+                push(EV_NOTIFY, now, kNormal | (eid + 2));
+            }
+            eid += 3;
+            n_tx++;
+            break;
+        }
+        case EV_NOTIFY: {
+            const double stop_dev = __shfl(L.tx_stop, dev, 64);
+            if (me && lane != dev) {                      // _onNewTransmission at every other radio
+                const double p = s_prx[dev * n + lane];
+                L.rx_power = L.rx_power + p;
+                if (L.receiving) power_changed();
+            }
+            // receive-process admission, blocking and not queued, in radio order (the sender too)
+            const bool start = me && !L.rx_running;
+            const unsigned long long m = __ballot(start);
+            if (start) {
+                L.rx_running = 1;
+                L.rxi_src = dev;
+                L.rxi_stop = stop_dev;
+                push(EV_RXINIT, now, eid + lanes_below(m, lane));        // URGENT
+            }
+            eid += __popcll(m);
+            break;
+        }
+        case EV_RXINIT: {
+            int inc = 0;
+            if (mine) {
+                if (!L.transmitting) {                    // simple_stack.py:216-235
+                    L.receiving = 1;
+                    L.rx_src = L.rxi_src;
+                    L.rx_stop = L.rxi_stop;
+                    L.rx_phase = 0;
+                    L.err_sum = 0.0;
+                    L.t_seg = now;
+                    const double sig = s_prx[L.rx_src * n + lane];
+                    const double noise = L.rx_power - sig;
+                    if (!(noise >= 0)) L.flags |= GW_FLAG_REFEXC;
+                    L.ber = ber_bpsk(sig, noise, g.ten_log_br, g.sqrt2pi);
+                } else {
+                    push(EV_RXPROC, now, kNormal | eid);  // the generator ends at once
+                    inc = 1;
+                }
+            }
+            eid += __shfl(inc, dev, 64);
+            break;
+        }
+        case EV_HDR: {                                    // receivers of `dev` in the header phase, radio order
+            const bool rx = me && L.receiving && L.rx_src == dev && L.rx_phase == 0;
+            bool fail = false;
+            if (rx) {
+                L.err_sum += L.ber * (now - L.t_seg) * br;
+                if (4.0 * rint(L.err_sum) <= hdr_bits) {  // round(err)/bits <= 0.25, bits integral
+                    L.hdr_ok++;
+                    L.rx_phase = 1;
+                    L.err_sum = 0.0;
+                    L.t_seg = now;
+                    const double sig = s_prx[dev * n + lane];
+                    const double noise = L.rx_power - sig;
+                    if (!(noise >= 0)) L.flags |= GW_FLAG_REFEXC;
+                    L.ber = ber_bpsk(sig, noise, g.ten_log_br, g.sqrt2pi);
+                } else {
+                    L.hdr_fail++;
+                    fail = true;
+                }
+            }
+            // a failing receiver: [RXFIN if its handler waits] then RXPROC, lane by lane
+            const int pushes = fail ? (L.waiting_rx ? 2 : 1) : 0;
+            int before = pushes;                          // exclusive prefix sum over lanes
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(before, off, 64); if (lane >= off) before += v; }
+            const int total = __shfl(before, 63, 64);
+            before -= pushes;
+            if (fail) {
+                L.receiving = 0; L.err_sum = 0.0; L.ber = 0.0; L.t_seg = now;
+                uint32_t e0 = eid + before;
+                if (L.waiting_rx) { L.waiting_rx = 0; push(EV_RXFIN, now, kNormal | e0); e0++; }
+                push(EV_RXPROC, now, kNormal | e0);
+            }
+            eid += total;
+            break;
+        }
+        case EV_END: {
+            // (1) the sender's handler resumes: cmd done event, then its process event
+            if (mine) { L.transmitting = 0; push(EV_HPROC, now, kNormal | (eid + 1)); }
+            eid += 2;
+            // (2) every other radio: the power goes away; receivers re-integrate
+            if (me && lane != dev) {
+                const double p = s_prx[dev * n + lane];
+                L.rx_power = L.rx_power + (-p);
+                if (L.receiving) {
+                    if (L.rx_src == dev && !(now >= L.rx_stop)) L.flags |= GW_FLAG_REFEXC;   // KeyError in the reference
+                    power_changed();
+                }
+            }
+            // (3) payload decisions of the radios that received this transmission, radio order
+            const bool rx = me && L.receiving && L.rx_src == dev && L.rx_phase == 1;
+            if (rx) {
+                L.err_sum += L.ber * (now - L.t_seg) * br;               // counted a second time (:252)
+                if (4.0 * rint(L.err_sum) <= pay_bits) L.pay_ok++; else L.pay_fail++;
+            }
+            const int pushes = rx ? (L.waiting_rx ? 2 : 1) : 0;
+            int before = pushes;
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(before, off, 64); if (lane >= off) before += v; }
+            const int total = __shfl(before, 63, 64);
+            before -= pushes;
+            if (rx) {
+                L.receiving = 0; L.err_sum = 0.0; L.ber = 0.0; L.t_seg = now;
+                uint32_t e0 = eid + before;
+                if (L.waiting_rx) { L.waiting_rx = 0; push(EV_RXFIN, now, kNormal | e0); e0++; }
+                push(EV_RXPROC, now, kNormal | e0);
+            }
+            eid += total;
+            break;
+        }
+        case EV_RXPROC: {
+            if (mine) L.rx_running = 0;
+            break;
+        }
+        case EV_HPROC: {                                  // queued SEND commands (simtools.py:369-381)
+            int inc = 0;
+            if (mine) {
+                if (L.queued) { L.queued--; push(EV_HINIT, now, eid); inc = 1; }        // URGENT
+                else L.handler_running = 0;
+            }
+            eid += __shfl(inc, dev, 64);
+            break;
+        }
+        }
+    }
+
+    // ---- registers -> state -----------------------------------------------------------------------------
+    if (me) g.lanes[env * n + lane] = L;
+    if (lane == 0) {
+        E.now = now; E.eid = eid; E.events = n_events; E.n_tx = n_tx;
+        g.envs[env] = E;
+    }
+}
+
+__global__ void grid_init_kernel(GwGridDev g, const double* __restrict__ delays, double thermal)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= g.N * g.n) return;
+    const int64_t env = idx / g.n;
+    const int dev = (int)(idx - env * g.n);
+    GwGridLane L;
+    memset(&L, 0, sizeof L);
+    for (int k = 0; k < EV_COUNT; ++k) { L.ev_t[k] = kInf; L.ev_k[k] = 0xffffffffu; }
+    // insertion ids at start-up: process inits of device 0..n-1 take 0..n-1; run() is called before
+    // they are processed, so the first stop event is id n; each init then yields timeout(initial_delay):
+    // ids n+1 .. 2n.
+    L.ev_t[EV_TICK] = 0.0 + delays[idx];
+    L.ev_k[EV_TICK] = kNormal | (uint32_t)(g.n + 1 + dev);
+    L.rx_power = thermal;
+    g.lanes[idx] = L;
+    if (dev == 0) {
+        GwGridEnv E;
+        memset(&E, 0, sizeof E);
+        E.now = 0.0;
+        E.eid = (uint32_t)(2 * g.n + 1);
+        E.first_run = 1;                                 // the first run's stop event has id n
+        g.envs[env] = E;
+    }
+}
+
+} // namespace
+
+int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream)
+{
+    const size_t lds = (size_t)g.n * g.n * sizeof(double);
+    hipLaunchKernelGGL(grid_run_kernel, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
+int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, double thermal, void* stream)
+{
+    const int64_t total = g.N * g.n;
+    hipLaunchKernelGGL(grid_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, delays_dev, thermal);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}

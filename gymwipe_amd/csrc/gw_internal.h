@@ -90,6 +90,28 @@ struct GwPlantDev {
     double dt, inv_dt;
 };
 
+// PHY grid (grid_phy.hip, gw_grid_api.cpp)
+#define GW_GRID_EVENTS 10
+struct GwGridLane {                     // one radio of one replica
+    double   ev_t[GW_GRID_EVENTS];      // pending events of this device: time (+inf = none) ...
+    uint32_t ev_k[GW_GRID_EVENTS];      // ... and key = priority bit | insertion id
+    double   rx_power, tx_stop, rx_stop, rxi_stop, err_sum, ber, t_seg;
+    uint32_t n_sent, queued, hdr_ok, hdr_fail, pay_ok, pay_fail, flags;
+    int32_t  rx_src, rxi_src;
+    uint8_t  started, handler_running, transmitting, receiving, waiting_rx, rx_running, rx_phase, pad;
+};
+struct GwGridEnv { double now; uint32_t eid, events, n_tx, first_run; };
+struct GwGridDev {
+    int64_t N; int32_t n, pad;
+    GwGridLane* lanes;                  // [N][n]
+    GwGridEnv*  envs;                   // [N]
+    const double* prx;                  // [n from][n to] received power, mW
+    double slot, send_interval, bit_rate, hdr_bits, pay_bits, hdr_dur, pay_dur, ten_log_br, sqrt2pi;
+    uint32_t max_events, pad2;          // bound on events per launch (a logic error must not hang the GPU)
+};
+int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream);
+int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, double thermal, void* stream);
+
 // Host-side link tables (gw_tables.cpp)
 struct GwHostTables {
     int D, R;

@@ -191,6 +191,46 @@ int gw_plant_get_state(gw_plant* p, const char* field, void* dst_host, size_t by
 /* device pointer + stride of the per-env simulated time of a gw_env (default mode), for gw_plant_update */
 int gw_now_ptr(gw_env* env, const void** now_dev, int64_t* stride_bytes);
 
+/* ---------------------------------------------------------------------------------------------------
+ * PHY grid: N independent replicas of the reference's benchmark scenario
+ * (tests/test_benchmark.py:20-91) -- n uncoordinated PHY-only devices, each sending one 39-byte packet
+ * every 10 ms at 40 dBm from its own phase.  The one workload of the reference with CONCURRENT
+ * transmissions: every radio sums the power of all active transmissions (simple_stack.py:99-157) and
+ * re-integrates its bit errors at every power change (:161-188,:214-267); a device that wants to send
+ * while receiving waits for the reception to end (:199-200).
+ *   replaces  SimMan.runSimulation(seconds) over SendingDevice / SimplePhy / FrequencyBand
+ * One wave per replica, one lane per radio; events are popped in SimPy's (time, priority, insertion id)
+ * order.  Integer outcomes are compared bit-exact with the event-driven oracle; BER uses the device
+ * libm (log10/pow/sqrt), so floating-point state is compared to 1e-9 relative.
+ * ------------------------------------------------------------------------------------------------- */
+#define GW_GRID_MAX_DEVICES 64
+
+typedef struct gw_grid_config {
+    int32_t abi_version;                    /* GW_ABI_VERSION */
+    int32_t hip_device;
+    int64_t num_envs;                       /* replicas */
+    int32_t num_devices;                    /* n <= GW_GRID_MAX_DEVICES */
+    int32_t reserved;
+    double  pos[GW_GRID_MAX_DEVICES][2];    /* metres (default: (i / cols, i % cols), cols = int(sqrt(n))) */
+    double  slot, frequency, bandwidth, temperature_c, bit_rate, code_rate, max_ber;
+    double  tx_power_dbm;                   /* 40.0   tests/test_benchmark.py:47 */
+    double  send_interval;                  /* 1e-2   :17 */
+    int32_t header_bytes;                   /* 13 */
+    int32_t payload_bytes;                  /* 26 = len("A message to all my homies") */
+} gw_grid_config;
+
+typedef struct gw_grid gw_grid;
+
+int gw_grid_config_default(gw_grid_config* cfg, int64_t num_envs, int32_t num_devices);
+/* initial_delays_host: double[N][n], the random.uniform(0, SEND_INTERVAL) of tests/test_benchmark.py:67 */
+int gw_grid_create(const gw_grid_config* cfg, const double* initial_delays_host, gw_grid** out);
+int gw_grid_destroy(gw_grid* g);
+/* SimMan.runSimulation(seconds) for every replica */
+int gw_grid_run(gw_grid* g, double seconds, void* stream);
+/* host copies: "now" f64[N] | "events","n_tx","flags" u32[N] | "n_sent","hdr_ok","hdr_fail","pay_ok","pay_fail" u32[N][n]
+ *              | "rx_power" f64[N][n] */
+int gw_grid_get_state(gw_grid* g, const char* field, void* dst_host, size_t bytes);
+
 /* Host-only self-test hook (no GPU needed): fuzzes the MAC-queue encoding the default kernel uses
  * against an explicit deque(maxlen=100).  Returns the number of mismatches (0 = identical). */
 int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);

@@ -1,0 +1,48 @@
+"""
+PHY grid (the reference's benchmark scenario tests/test_benchmark.py:20-91): the HIP
+event-queue kernel against the event-driven oracle (oracle/des_model.py scenario_grid) on the same initial
+delays.  Integer outcomes (packets sent, transmissions, header/payload decisions per radio) bit-exact;
+floating-point state (received power, simulated time) to 1e-9 relative -- the kernel evaluates the BER
+with the device libm.  PARITY vs the live reference: unpinned (the reference asserts nothing here; it
+is a timing benchmark) -- the oracle's PHY is pinned by tests/networking/test_stack.py:65-132.
+"""
+import numpy as np
+import pytest
+
+
+def test_grid_oracle_scenario_is_deterministic_and_collides():
+    from oracle import des_model as dm
+    rng = np.random.default_rng(3)
+    d = rng.uniform(0, 1e-2, 9).tolist()
+    a, b = dm.scenario_grid(9, d, 0.12), dm.scenario_grid(9, d, 0.12)
+    assert a == b
+    assert sum(a["n_sent"]) >= 9 * 10 and a["n_tx"] <= sum(a["n_sent"])
+    assert sum(a["hdr_fail"]) > 0                      # uncoordinated senders do collide
+    assert dm.grid_positions(4) == [(0.0, 0.0), (0.5, 1.0), (1.0, 0.0), (1.5, 1.0)]   # (i / cols, i % cols)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,N,T", [(2, 6, 0.25), (4, 6, 0.2), (9, 5, 0.15), (16, 4, 0.12), (20, 2, 0.08)])
+def test_grid_kernel_matches_event_driven_oracle(n, N, T):
+    import gymwipe_amd
+    from oracle import des_model as dm
+    rng = np.random.default_rng(100 + n)
+    delays = rng.uniform(0, 1e-2, (N, n))
+    grid = gymwipe_amd.VecPhyGrid(N, n, delays)
+    grid.runSimulation(T * 0.4)                         # two runs: the second stop event gets a later id
+    grid.runSimulation(T * 0.6)
+    got = {f: grid.get_state(f) for f in ("now", "n_tx", "n_sent", "hdr_ok", "hdr_fail", "pay_ok", "pay_fail", "rx_power", "flags")}
+    for e in range(N):
+        w = dm.World()
+        devs = [dm.GridDevice(w, i, *dm.grid_positions(n)[i], dm.GRID_SEND_INTERVAL, float(delays[e, i])) for i in range(n)]
+        w.sim.run(T * 0.4)
+        w.sim.run(T * 0.6)
+        assert got["now"][e] == w.sim.now
+        assert got["n_sent"][e].tolist() == [d.n_sent for d in devs], "env %d" % e
+        assert int(got["n_tx"][e]) == len(w.band.log), "env %d" % e
+        for key, what, ok in (("hdr_ok", "hdr", True), ("hdr_fail", "hdr", False), ("pay_ok", "pay", True), ("pay_fail", "pay", False)):
+            want = [sum(1 for k in d.phy.decisions if k[0] == what and k[1] is ok) for d in devs]
+            assert got[key][e].tolist() == want, "%s env %d: %s vs %s" % (key, e, got[key][e].tolist(), want)
+        rx = np.array([d.phy.rx_power for d in devs])
+        assert np.allclose(got["rx_power"][e], rx, rtol=1e-9, atol=0.0)
+        assert int(got["flags"][e]) == 0

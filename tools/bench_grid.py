@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""The reference's benchmark_simulation_grid (tests/test_benchmark.py:87-88: wall time of 1 simulated second of an
+n-device grid), as N replicas on one MI355X; plus the event-driven oracle (pure Python, one core) on the same
+scenario as the CPU figure.  Prints one JSON line per n."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import gymwipe_amd
+
+N = int(os.environ.get("N", 4096))
+SIM = float(os.environ.get("SIM", 1.0))
+for n in (4, 16, 20):
+    rng = np.random.default_rng(n)
+    delays = rng.uniform(0, 1e-2, (N, n))
+    grid = gymwipe_amd.VecPhyGrid(N, n, delays)
+    grid.runSimulation(0.05)                       # warm-up (also past the start-up transient)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    grid.runSimulation(SIM)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev = grid.get_state("events").astype(np.int64)
+    out = {"workload": "PHY grid, %d devices, %d replicas, %.2f s simulated each (static)" % (n, N, SIM),
+           "replica_seconds_per_s": N * SIM / wall, "wall_s": wall, "events_total": int(ev.sum()),
+           "events_per_s": float(ev.sum()) / (wall * (SIM + 0.05) / SIM), "n_tx_mean": float(grid.get_state("n_tx").mean()),
+           "hdr_ok": int(grid.get_state("hdr_ok").sum()), "hdr_fail": int(grid.get_state("hdr_fail").sum()),
+           "flags_or": int(np.bitwise_or.reduce(grid.get_state("flags")))}
+    if not os.environ.get("NO_CPU"):
+        from oracle import des_model as dm
+        t1 = time.perf_counter()
+        dm.scenario_grid(n, delays[0].tolist(), min(SIM, 0.5))
+        cpu = time.perf_counter() - t1
+        out["cpu_oracle_python_1core_wall_per_sim_s"] = cpu / min(SIM, 0.5)
+        out["speedup_vs_python_oracle"] = out["replica_seconds_per_s"] * out["cpu_oracle_python_1core_wall_per_sim_s"]
+    print(json.dumps(out))
+    grid.close()

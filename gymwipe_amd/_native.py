@@ -79,12 +79,13 @@ GRID_MAX_DEVICES = 64
 class GridConfig(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("hip_device", C.c_int32), ("num_envs", C.c_int64),
-        ("num_devices", C.c_int32), ("reserved", C.c_int32),
+        ("num_devices", C.c_int32), ("mobile", C.c_int32),
         ("pos", (C.c_double * 2) * GRID_MAX_DEVICES),
         ("slot", C.c_double), ("frequency", C.c_double), ("bandwidth", C.c_double), ("temperature_c", C.c_double),
         ("bit_rate", C.c_double), ("code_rate", C.c_double), ("max_ber", C.c_double),
         ("tx_power_dbm", C.c_double), ("send_interval", C.c_double),
         ("header_bytes", C.c_int32), ("payload_bytes", C.c_int32),
+        ("move_interval", C.c_double), ("move_span", C.c_double), ("seed", C.c_uint64),
     ]
 
 

@@ -29,7 +29,8 @@
 
 namespace {
 
-enum { EV_TICK = 0, EV_HINIT, EV_SLOT, EV_RXFIN, EV_HDR, EV_END, EV_NOTIFY, EV_RXINIT, EV_RXPROC, EV_HPROC, EV_COUNT };
+enum { EV_TICK = 0, EV_HINIT, EV_SLOT, EV_RXFIN, EV_HDR, EV_END, EV_NOTIFY, EV_RXINIT, EV_RXPROC, EV_HPROC, EV_MOVE, EV_COUNT };
+static_assert(EV_COUNT == GW_GRID_EVENTS, "event slots");
 constexpr uint32_t kNormal = 0x80000000u;       // key = priority bit | insertion id
 constexpr double kInf = __builtin_inf();
 
@@ -46,11 +47,38 @@ __device__ __forceinline__ double ber_bpsk(double sig_mw, double noise_mw, doubl
     return (1 - pow(e, -1.4 * x)) * pow(e, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
 }
 
+// counter-based generator shared with the oracle (des_model.grid_uniform)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double grid_uniform(unsigned long long seed, unsigned long long replica, unsigned device,
+                                               unsigned k, unsigned which)
+{
+    unsigned long long h = splitmix64(seed * 0x100000001B3ull + replica);
+    h = splitmix64(h ^ (unsigned long long)(device * 0x9E3779B1ull + k));
+    h = splitmix64(h ^ which);
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// FsplAttenuation._update + dbmToMilliwatts with the device libm (attenuation_models.py:28-36, physical.py:98)
+__device__ __forceinline__ double fspl_power(double ax, double ay, double bx, double by, double tx_dbm, double twenty_log_f)
+{
+    const double dist = sqrt(pow(ax - bx, 2.0) + pow(ay - by, 2.0));
+    const double att = 20 * log10(dist) + twenty_log_f - 147.55;
+    return pow(10.0, (tx_dbm - att) / 10);
+}
+
 __device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
 {
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+template <bool MOBILE>
 __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double seconds)
 {
     const int lane = threadIdx.x;
@@ -59,17 +87,23 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
     const bool me = lane < n;                            // this lane is a radio
 
     // ---- static link table -> LDS: prx[from][to] (mW) -------------------------------------------------
+    // static: prx[from][to]; mobile: the power each radio STORED for each active transmission
+    // (simple_stack.py:78,136), plus the current positions
     extern __shared__ double s_prx[];
-    for (int i = lane; i < n * n; i += 64) s_prx[i] = g.prx[i];
-    __syncthreads();
+    double* s_px = s_prx + n * n;
+    double* s_py = s_px + n;
+    if (MOBILE) { for (int i = lane; i < n * n; i += 64) s_prx[i] = g.txp[env * n * n + i]; }
+    else        { for (int i = lane; i < n * n; i += 64) s_prx[i] = g.prx[i]; }
 
     // ---- state -> registers -----------------------------------------------------------------------------
     GwGridLane L;
     if (me) L = g.lanes[env * n + lane];
     else {
         for (int k = 0; k < EV_COUNT; ++k) { L.ev_t[k] = kInf; L.ev_k[k] = 0xffffffffu; }
-        L.rx_power = 0; L.flags = 0;
+        L.rx_power = 0; L.flags = 0; L.px = 0; L.py = 0; L.tx_on = 0;
     }
+    if (MOBILE && me) { s_px[lane] = L.px; s_py[lane] = L.py; }
+    __syncthreads();
     GwGridEnv E = g.envs[env];                           // wave-uniform: now, eid, counters
     double now = E.now;
     uint32_t eid = E.eid;
@@ -78,7 +112,11 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
     const double t_stop = now + seconds;
     const double t_stop_at = now + (t_stop - now);
     uint32_t k_stop;                                     // URGENT: priority bit clear
-    if (E.first_run) { k_stop = (uint32_t)n; eid = (uint32_t)(2 * n + 1); E.first_run = 0; }   // see grid_init_kernel
+    if (E.first_run) {                                   // see grid_init_kernel
+        k_stop = (uint32_t)(MOBILE ? 2 * n : n);
+        eid = (uint32_t)(MOBILE ? 4 * n + 1 : 2 * n + 1);
+        E.first_run = 0;
+    }
     else k_stop = eid++;
 
     const double slot = g.slot, interval = g.send_interval, br = g.bit_rate;
@@ -170,8 +208,13 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
         }
         case EV_NOTIFY: {
             const double stop_dev = __shfl(L.tx_stop, dev, 64);
+            if (mine) L.tx_on = 1;
             if (me && lane != dev) {                      // _onNewTransmission at every other radio
-                const double p = s_prx[dev * n + lane];
+                double p;
+                if (MOBILE) {
+                    p = fspl_power(L.px, L.py, s_px[dev], s_py[dev], g.tx_power_dbm, g.twenty_log_f);
+                    s_prx[dev * n + lane] = p;            // _transmissionToReceivedPower[t]
+                } else p = s_prx[dev * n + lane];
                 L.rx_power = L.rx_power + p;
                 if (L.receiving) power_changed();
             }
@@ -245,7 +288,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
         }
         case EV_END: {
             // (1) the sender's handler resumes: cmd done event, then its process event
-            if (mine) { L.transmitting = 0; push(EV_HPROC, now, kNormal | (eid + 1)); }
+            if (mine) { L.transmitting = 0; L.tx_on = 0; push(EV_HPROC, now, kNormal | (eid + 1)); }
             eid += 2;
             // (2) every other radio: the power goes away; receivers re-integrate
             if (me && lane != dev) {
@@ -280,6 +323,53 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
             if (mine) L.rx_running = 0;
             break;
         }
+        case EV_MOVE: {                                   // mover process: tests/test_benchmark.py:73-85
+            if (MOBILE) {
+                if (mine) {
+                    const double xo = -g.move_span + (g.move_span - (-g.move_span)) * grid_uniform(g.seed, (unsigned long long)env, (unsigned)lane, L.move_k, 1u);
+                    const double yo = -g.move_span + (g.move_span - (-g.move_span)) * grid_uniform(g.seed, (unsigned long long)env, (unsigned)lane, L.move_k, 2u);
+                    L.px = L.px + xo;
+                    L.py = L.py + yo;
+                    L.move_k++;
+                    s_px[lane] = L.px; s_py[lane] = L.py;
+                    push(EV_MOVE, now + g.move_interval, kNormal | eid);
+                }
+                eid += 1;
+                __syncthreads();
+                const unsigned long long on_air = __ballot(me && L.tx_on);
+                // (A) the mover's own transmission, heard by everyone else: _onAttenuationChange (simple_stack.py:119-128)
+                if ((on_air >> dev) & 1ull) {
+                    if (me && lane != dev) {
+                        const double dx = L.px - s_px[dev], dy = L.py - s_py[dev];
+                        if (sqrt(dx * dx + dy * dy) < 3000.0) {              // STANDBY_THRESHOLD, physical.py:371-386
+                            const double np_ = fspl_power(L.px, L.py, s_px[dev], s_py[dev], g.tx_power_dbm, g.twenty_log_f);
+                            const double delta = np_ - s_prx[dev * n + lane];
+                            s_prx[dev * n + lane] = np_;
+                            L.rx_power = L.rx_power + delta;
+                            if (L.receiving && delta != 0) power_changed();
+                        }
+                    }
+                }
+                // (B) every other transmission on the air, as heard by the mover
+                if (mine) {
+                    unsigned long long rest = on_air & ~(1ull << dev);
+                    while (rest) {
+                        const int i = __ffsll((long long)rest) - 1;
+                        rest &= rest - 1;
+                        const double dx = L.px - s_px[i], dy = L.py - s_py[i];
+                        if (sqrt(dx * dx + dy * dy) < 3000.0) {
+                            const double np_ = fspl_power(s_px[i], s_py[i], L.px, L.py, g.tx_power_dbm, g.twenty_log_f);
+                            const double delta = np_ - s_prx[i * n + lane];
+                            s_prx[i * n + lane] = np_;
+                            L.rx_power = L.rx_power + delta;
+                            if (L.receiving && delta != 0) power_changed();
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            break;
+        }
         case EV_HPROC: {                                  // queued SEND commands (simtools.py:369-381)
             int inc = 0;
             if (mine) {
@@ -293,6 +383,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
     }
 
     // ---- registers -> state -----------------------------------------------------------------------------
+    if (MOBILE) { __syncthreads(); for (int i = lane; i < n * n; i += 64) g.txp[env * n * n + i] = s_prx[i]; }
     if (me) g.lanes[env * n + lane] = L;
     if (lane == 0) {
         E.now = now; E.eid = eid; E.events = n_events; E.n_tx = n_tx;
@@ -300,7 +391,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
     }
 }
 
-__global__ void grid_init_kernel(GwGridDev g, const double* __restrict__ delays, double thermal)
+__global__ void grid_init_kernel(GwGridDev g, const double* __restrict__ delays, const double* __restrict__ pos, double thermal)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= g.N * g.n) return;
@@ -312,16 +403,22 @@ __global__ void grid_init_kernel(GwGridDev g, const double* __restrict__ delays,
     // insertion ids at start-up: process inits of device 0..n-1 take 0..n-1; run() is called before
     // they are processed, so the first stop event is id n; each init then yields timeout(initial_delay):
     // ids n+1 .. 2n.
+    // mobile: sender inits 0..n-1, mover inits n..2n-1, stop 2n, delay timeouts 2n+1..3n, first moves 3n+1..4n
     L.ev_t[EV_TICK] = 0.0 + delays[idx];
-    L.ev_k[EV_TICK] = kNormal | (uint32_t)(g.n + 1 + dev);
+    L.ev_k[EV_TICK] = kNormal | (uint32_t)((g.mobile ? 2 * g.n : g.n) + 1 + dev);
+    if (g.mobile) {
+        L.ev_t[EV_MOVE] = 0.0 + grid_uniform(g.seed, (unsigned long long)env, (unsigned)dev, 0u, 0u) * g.move_interval;
+        L.ev_k[EV_MOVE] = kNormal | (uint32_t)(3 * g.n + 1 + dev);
+    }
+    L.px = pos[dev * 2]; L.py = pos[dev * 2 + 1];
     L.rx_power = thermal;
     g.lanes[idx] = L;
     if (dev == 0) {
         GwGridEnv E;
         memset(&E, 0, sizeof E);
         E.now = 0.0;
-        E.eid = (uint32_t)(2 * g.n + 1);
-        E.first_run = 1;                                 // the first run's stop event has id n
+        E.eid = (uint32_t)((g.mobile ? 4 : 2) * g.n + 1);
+        E.first_run = 1;                                 // the first run's stop event has id n (2n when mobile)
         g.envs[env] = E;
     }
 }
@@ -330,14 +427,15 @@ __global__ void grid_init_kernel(GwGridDev g, const double* __restrict__ delays,
 
 int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream)
 {
-    const size_t lds = (size_t)g.n * g.n * sizeof(double);
-    hipLaunchKernelGGL(grid_run_kernel, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
+    const size_t lds = ((size_t)g.n * g.n + 2 * (size_t)g.n) * sizeof(double);
+    if (g.mobile) hipLaunchKernelGGL(grid_run_kernel<true>, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
+    else          hipLaunchKernelGGL(grid_run_kernel<false>, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
-int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, double thermal, void* stream)
+int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, const double* pos_dev, double thermal, void* stream)
 {
     const int64_t total = g.N * g.n;
-    hipLaunchKernelGGL(grid_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, delays_dev, thermal);
+    hipLaunchKernelGGL(grid_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, delays_dev, pos_dev, thermal);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }

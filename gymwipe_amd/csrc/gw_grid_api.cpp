@@ -13,7 +13,7 @@ int gw_set_error(int code, const char* fmt, ...);      // gw_api.cpp
 struct gw_grid {
     gw_grid_config cfg;
     GwGridDev dev;
-    void* blocks[4];
+    void* blocks[6];
     int nblocks;
 };
 
@@ -44,6 +44,9 @@ int gw_grid_config_default(gw_grid_config* c, int64_t num_envs, int32_t n)
     c->send_interval = 1e-2;                                     // :17
     c->header_bytes = 13;                                        // SimpleMacHeader
     c->payload_bytes = 26;                                       // "A message to all my homies" (:44)
+    c->move_interval = 1e-3;                                     // :18
+    c->move_span = 0.2;                                          // :79-80
+    c->seed = 0;
     return GW_OK;
 }
 
@@ -86,7 +89,7 @@ int gw_grid_create(const gw_grid_config* cfg, const double* delays, gw_grid** ou
 
     GwGridDev& d = g->dev;
     d.N = N; d.n = n;
-    double* d_prx = nullptr; double* d_delays = nullptr;
+    double* d_prx = nullptr; double* d_delays = nullptr; double* d_pos = nullptr; double* d_txp = nullptr;
     auto alloc = [&](void** p, size_t bytes) {
         if (hipMalloc(p, bytes) != hipSuccess) return false;
         g->blocks[g->nblocks++] = *p;
@@ -97,7 +100,9 @@ int gw_grid_create(const gw_grid_config* cfg, const double* delays, gw_grid** ou
         gw_grid_destroy(g);
         return gw_set_error(GW_ENOMEM, "hipMalloc failed in gw_grid_create");
     }
-    if (hipMalloc((void**)&d_delays, (size_t)N * n * sizeof(double)) != hipSuccess) { gw_grid_destroy(g); return gw_set_error(GW_ENOMEM, "hipMalloc failed"); }
+    if (cfg->mobile && !alloc((void**)&d_txp, (size_t)N * n * n * sizeof(double))) { gw_grid_destroy(g); return gw_set_error(GW_ENOMEM, "hipMalloc failed"); }
+    if (hipMalloc((void**)&d_delays, ((size_t)N * n + 2 * (size_t)n) * sizeof(double)) != hipSuccess) { gw_grid_destroy(g); return gw_set_error(GW_ENOMEM, "hipMalloc failed"); }
+    d_pos = d_delays + (size_t)N * n;
     d.prx = d_prx;
     d.slot = cfg->slot; d.send_interval = cfg->send_interval; d.bit_rate = cfg->bit_rate;
     {
@@ -106,11 +111,19 @@ int gw_grid_create(const gw_grid_config* cfg, const double* delays, gw_grid** ou
         d.hdr_dur = hb / data_rate; d.pay_dur = pb / data_rate;   // :244-247
     }
     d.max_events = 0;                                   // set per run from the simulated span
+    d.mobile = cfg->mobile ? 1u : 0u; d.move_interval = cfg->move_interval; d.move_span = cfg->move_span;
+    d.tx_power_dbm = cfg->tx_power_dbm; d.twenty_log_f = 20 * log10(cfg->frequency); d.txp = d_txp; d.seed = cfg->seed;
     d.ten_log_br = 10 * log10(cfg->bit_rate);
     d.sqrt2pi = sqrt(2 * M_PI);
     GRID_HIP(hipMemcpy(d_prx, prx.data(), prx.size() * sizeof(double), hipMemcpyHostToDevice), ((void)hipFree(d_delays), gw_grid_destroy(g)));
     GRID_HIP(hipMemcpy(d_delays, delays, (size_t)N * n * sizeof(double), hipMemcpyHostToDevice), ((void)hipFree(d_delays), gw_grid_destroy(g)));
-    if (gw_grid_launch_init(d, d_delays, thermal, nullptr)) { (void)hipFree(d_delays); gw_grid_destroy(g); return gw_set_error(GW_EHIP, "grid init launch failed"); }
+    {
+        std::vector<double> pos((size_t)2 * n);
+        for (int i = 0; i < n; ++i) { pos[2 * i] = cfg->pos[i][0]; pos[2 * i + 1] = cfg->pos[i][1]; }
+        GRID_HIP(hipMemcpy(d_pos, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice), ((void)hipFree(d_delays), gw_grid_destroy(g)));
+        if (d_txp) GRID_HIP(hipMemset(d_txp, 0, (size_t)N * n * n * sizeof(double)), ((void)hipFree(d_delays), gw_grid_destroy(g)));
+    }
+    if (gw_grid_launch_init(d, d_delays, d_pos, thermal, nullptr)) { (void)hipFree(d_delays); gw_grid_destroy(g); return gw_set_error(GW_EHIP, "grid init launch failed"); }
     GRID_HIP(hipDeviceSynchronize(), ((void)hipFree(d_delays), gw_grid_destroy(g)));
     (void)hipFree(d_delays);
     *out = g;
@@ -132,7 +145,8 @@ int gw_grid_run(gw_grid* g, double seconds, void* stream)
     if (!(seconds > 0)) return gw_set_error(GW_EINVAL, "seconds must be positive");
     GRID_HIP(hipSetDevice(g->cfg.hip_device), (void)0);
     // ~12 events per packet, one packet per device and send interval; generous factor on top
-    const double expect = 12.0 * g->dev.n * (seconds / g->cfg.send_interval + 2.0);
+    const double expect = 12.0 * g->dev.n * (seconds / g->cfg.send_interval + 2.0)
+                        + (g->cfg.mobile ? g->dev.n * (seconds / g->cfg.move_interval + 2.0) : 0.0);
     g->dev.max_events = (uint32_t)(expect * 8.0 < 4.0e9 ? expect * 8.0 + 1000.0 : 4.0e9);
     if (gw_grid_launch_run(g->dev, seconds, stream)) return gw_set_error(GW_EHIP, "grid run launch failed");
     return GW_OK;
@@ -155,6 +169,11 @@ int gw_grid_get_state(gw_grid* g, const char* field, void* dst, size_t bytes)
     if (!strcmp(field, "flags")) {
         NEEDB(N, uint32_t);
         for (int64_t e = 0; e < N; ++e) { uint32_t f = 0; for (int i = 0; i < n; ++i) f |= lanes[(size_t)e * n + i].flags; ((uint32_t*)dst)[e] = f; }
+        return GW_OK;
+    }
+    if (!strcmp(field, "pos")) {
+        NEEDB(N * n * 2, double);
+        for (size_t i = 0; i < lanes.size(); ++i) { ((double*)dst)[2 * i] = lanes[i].px; ((double*)dst)[2 * i + 1] = lanes[i].py; }
         return GW_OK;
     }
     if (!strcmp(field, "rx_power")) { NEEDB(N * n, double); for (size_t i = 0; i < lanes.size(); ++i) ((double*)dst)[i] = lanes[i].rx_power; return GW_OK; }

@@ -91,11 +91,12 @@ struct GwPlantDev {
 };
 
 // PHY grid (grid_phy.hip, gw_grid_api.cpp)
-#define GW_GRID_EVENTS 10
+#define GW_GRID_EVENTS 11
 struct GwGridLane {                     // one radio of one replica
     double   ev_t[GW_GRID_EVENTS];      // pending events of this device: time (+inf = none) ...
     uint32_t ev_k[GW_GRID_EVENTS];      // ... and key = priority bit | insertion id
-    double   rx_power, tx_stop, rx_stop, rxi_stop, err_sum, ber, t_seg;
+    double   rx_power, tx_stop, rx_stop, rxi_stop, err_sum, ber, t_seg, px, py;
+    uint32_t move_k, tx_on;             // moves made so far; 1 while this device's transmission is on the air (NOTIFY..END)
     uint32_t n_sent, queued, hdr_ok, hdr_fail, pay_ok, pay_fail, flags;
     int32_t  rx_src, rxi_src;
     uint8_t  started, handler_running, transmitting, receiving, waiting_rx, rx_running, rx_phase, pad;
@@ -107,10 +108,13 @@ struct GwGridDev {
     GwGridEnv*  envs;                   // [N]
     const double* prx;                  // [n from][n to] received power, mW
     double slot, send_interval, bit_rate, hdr_bits, pay_bits, hdr_dur, pay_dur, ten_log_br, sqrt2pi;
-    uint32_t max_events, pad2;          // bound on events per launch (a logic error must not hang the GPU)
+    uint32_t max_events, mobile;        // bound on events per launch (a logic error must not hang the GPU)
+    double   move_interval, move_span, tx_power_dbm, twenty_log_f;
+    double*  txp;                       // [N][n][n] mobile: received power of transmission i stored at radio j
+    unsigned long long seed;
 };
 int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream);
-int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, double thermal, void* stream);
+int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, const double* pos_dev, double thermal, void* stream);
 
 // Host-side link tables (gw_tables.cpp)
 struct GwHostTables {

@@ -13,7 +13,7 @@ from . import _native as nat
 class VecPhyGrid:
     SEND_INTERVAL = 1e-2                        # tests/test_benchmark.py:17
 
-    def __init__(self, num_envs, num_devices, initial_delays, device="cuda:0", positions=None):
+    def __init__(self, num_envs, num_devices, initial_delays, device="cuda:0", positions=None, mobile=False, seed=0):
         """``initial_delays``: float64[N][n], the per-device random.uniform(0, SEND_INTERVAL) of the fixture."""
         import torch
         if not torch.cuda.is_available():
@@ -28,6 +28,8 @@ class VecPhyGrid:
         if positions is not None:
             for i, (x, y) in enumerate(positions):
                 cfg.pos[i][0], cfg.pos[i][1] = float(x), float(y)
+        cfg.mobile = 1 if mobile else 0           # mobile_device_grid: every device random-walks every 1 ms
+        cfg.seed = int(seed)
         self.config = cfg
         d = np.ascontiguousarray(initial_delays, np.float64)
         assert d.shape == (self.num_envs, self.num_devices)
@@ -43,7 +45,7 @@ class VecPhyGrid:
     def get_state(self, field):
         N, n = self.num_envs, self.num_devices
         shapes = {"now": ((N,), np.float64), "events": ((N,), np.uint32), "n_tx": ((N,), np.uint32), "flags": ((N,), np.uint32),
-                  "rx_power": ((N, n), np.float64)}
+                  "rx_power": ((N, n), np.float64), "pos": ((N, n, 2), np.float64)}
         for k in ("n_sent", "hdr_ok", "hdr_fail", "pay_ok", "pay_fail"):
             shapes[k] = ((N, n), np.uint32)
         shape, dtype = shapes[field]

@@ -210,13 +210,16 @@ typedef struct gw_grid_config {
     int32_t hip_device;
     int64_t num_envs;                       /* replicas */
     int32_t num_devices;                    /* n <= GW_GRID_MAX_DEVICES */
-    int32_t reserved;
+    int32_t mobile;                         /* 1: every device also random-walks (mobile_device_grid, :73-85) */
     double  pos[GW_GRID_MAX_DEVICES][2];    /* metres (default: (i / cols, i % cols), cols = int(sqrt(n))) */
     double  slot, frequency, bandwidth, temperature_c, bit_rate, code_rate, max_ber;
     double  tx_power_dbm;                   /* 40.0   tests/test_benchmark.py:47 */
     double  send_interval;                  /* 1e-2   :17 */
     int32_t header_bytes;                   /* 13 */
     int32_t payload_bytes;                  /* 26 = len("A message to all my homies") */
+    double  move_interval;                  /* 1e-3   tests/test_benchmark.py:18 */
+    double  move_span;                      /* 0.2: offsets uniform(-span, span) per axis and move (:79-80) */
+    uint64_t seed;                          /* the walk of replica e, device i, move k is splitmix64(seed, e, i, k) */
 } gw_grid_config;
 
 typedef struct gw_grid gw_grid;
@@ -228,7 +231,7 @@ int gw_grid_destroy(gw_grid* g);
 /* SimMan.runSimulation(seconds) for every replica */
 int gw_grid_run(gw_grid* g, double seconds, void* stream);
 /* host copies: "now" f64[N] | "events","n_tx","flags" u32[N] | "n_sent","hdr_ok","hdr_fail","pay_ok","pay_fail" u32[N][n]
- *              | "rx_power" f64[N][n] */
+ *              | "rx_power" f64[N][n] | "pos" f64[N][n][2] */
 int gw_grid_get_state(gw_grid* g, const char* field, void* dst_host, size_t bytes);
 
 /* Host-only self-test hook (no GPU needed): fuzzes the MAC-queue encoding the default kernel uses

@@ -1115,3 +1115,54 @@ def scenario_grid(n, initial_delays, sim_time, moves=None, positions=None):
         out["pay_ok"].append(sum(1 for k in dec if k[0] == "pay" and k[1]))
         out["pay_fail"].append(sum(1 for k in dec if k[0] == "pay" and not k[1]))
     return out
+
+
+# ---- mobile variant (tests/test_benchmark.py:73-85) --------------------------------------------------
+# The fixture draws from Python's global Mersenne Twister; to let a GPU replica take the same walk, the
+# offsets come from a counter-based generator both sides can evaluate: splitmix64(seed, replica, device, k).
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def grid_uniform(seed, replica, device, k, which):
+    """U[0,1) with 53 random bits for draw `which` (0: first-move delay, 1: x offset, 2: y offset) of move k."""
+    h = splitmix64((seed * 0x100000001B3 + replica) & _M64)
+    h = splitmix64(h ^ ((device * 0x9E3779B1 + k) & _M64))
+    h = splitmix64(h ^ which)
+    return (h >> 11) * (1.0 / 9007199254740992.0)
+
+
+def scenario_mobile_grid(n, initial_delays, sim_time, seed=0, replica=0, runs=None):
+    """device_grid + mobile_device_grid: every device also runs a mover process that, from a random phase
+    in [0, MOVE_INTERVAL), shifts its position by uniform(-.2, .2) in x and y every MOVE_INTERVAL
+    (a random walk: `initialPos` aliases the live position object, tests/test_benchmark.py:76-82)."""
+    w = World()
+    pos = grid_positions(n)
+    devs = [GridDevice(w, i, pos[i][0], pos[i][1], GRID_SEND_INTERVAL, initial_delays[i]) for i in range(n)]
+    sim = w.sim
+
+    def mover(dv):
+        yield sim.timeout(grid_uniform(seed, replica, dv.index, 0, 0) * GRID_MOVE_INTERVAL)   # uniform(0, MOVE_INTERVAL)
+        k = 0
+        while True:
+            xo = -.2 + (.2 - -.2) * grid_uniform(seed, replica, dv.index, k, 1)              # random.uniform(-.2, .2)
+            yo = -.2 + (.2 - -.2) * grid_uniform(seed, replica, dv.index, k, 2)
+            dv.position.set(dv.position.x + xo, dv.position.y + yo)
+            k += 1
+            yield sim.timeout(GRID_MOVE_INTERVAL)
+    for dv in devs:
+        sim.process(mover(dv))
+    for t in (runs or [sim_time]):
+        sim.run(t)
+    out = {"n_sent": [d.n_sent for d in devs], "n_tx": len(w.band.log), "now": sim.now,
+           "rx_power": [d.phy.rx_power for d in devs], "pos": [(d.position.x, d.position.y) for d in devs]}
+    for key, what, ok in (("hdr_ok", "hdr", True), ("hdr_fail", "hdr", False), ("pay_ok", "pay", True), ("pay_fail", "pay", False)):
+        out[key] = [sum(1 for k in d.phy.decisions if k[0] == what and k[1] is ok) for d in devs]
+    return out

@@ -46,3 +46,37 @@ def test_grid_kernel_matches_event_driven_oracle(n, N, T):
         rx = np.array([d.phy.rx_power for d in devs])
         assert np.allclose(got["rx_power"][e], rx, rtol=1e-9, atol=0.0)
         assert int(got["flags"][e]) == 0
+
+
+def test_grid_rng_is_shared_with_the_oracle():
+    """The mobile walk is a counter-based hash both sides evaluate: check a few values of the oracle's
+    version (the kernel's copy is compared through positions in the GPU test below)."""
+    from oracle import des_model as dm
+    assert dm.splitmix64(0) == 0xE220A8397B1DCDAF
+    u = [dm.grid_uniform(7, 3, d, k, w) for d in (0, 5) for k in (0, 9) for w in (0, 1, 2)]
+    assert all(0.0 <= x < 1.0 for x in u) and len(set(u)) == len(u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,N,T", [(2, 4, 0.2), (4, 4, 0.15), (9, 3, 0.1), (16, 2, 0.07)])
+def test_mobile_grid_kernel_matches_event_driven_oracle(n, N, T):
+    """mobile_device_grid (tests/test_benchmark.py:73-85): positions change every 1 ms, so attenuation,
+    received power and BER move WHILE packets are being received (simple_stack.py:119-128,223-231)."""
+    import gymwipe_amd
+    from oracle import des_model as dm
+    rng = np.random.default_rng(500 + n)
+    delays = rng.uniform(0, 1e-2, (N, n))
+    seed = 1234
+    grid = gymwipe_amd.VecPhyGrid(N, n, delays, mobile=True, seed=seed)
+    grid.runSimulation(T * 0.5)
+    grid.runSimulation(T * 0.5)
+    got = {f: grid.get_state(f) for f in ("now", "n_tx", "n_sent", "hdr_ok", "hdr_fail", "pay_ok", "pay_fail", "rx_power", "pos", "flags")}
+    for e in range(N):
+        want = dm.scenario_mobile_grid(n, delays[e].tolist(), T, seed=seed, replica=e, runs=[T * 0.5, T * 0.5])
+        assert got["now"][e] == want["now"]
+        assert np.array_equal(got["pos"][e], np.array(want["pos"])), "the random walk itself must be bit-identical"
+        assert got["n_sent"][e].tolist() == want["n_sent"] and int(got["n_tx"][e]) == want["n_tx"], "env %d" % e
+        for key in ("hdr_ok", "hdr_fail", "pay_ok", "pay_fail"):
+            assert got[key][e].tolist() == want[key], "%s env %d: %s vs %s" % (key, e, got[key][e].tolist(), want[key])
+        assert np.allclose(got["rx_power"][e], np.array(want["rx_power"]), rtol=1e-7, atol=0.0)
+        assert int(got["flags"][e]) == 0

@@ -47,7 +47,7 @@ __device__ __forceinline__ double ber_bpsk(double sig_mw, double noise_mw, doubl
     return (1 - pow(e, -1.4 * x)) * pow(e, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
 }
 
-// counter-based generator shared with the oracle (des_model.grid_uniform)
+// counter-based generator (the test tree evaluates the same function to reproduce a replica's walk)
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
 {
     x += 0x9E3779B97F4A7C15ull;

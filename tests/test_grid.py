@@ -78,5 +78,8 @@ def test_mobile_grid_kernel_matches_event_driven_oracle(n, N, T):
         assert got["n_sent"][e].tolist() == want["n_sent"] and int(got["n_tx"][e]) == want["n_tx"], "env %d" % e
         for key in ("hdr_ok", "hdr_fail", "pay_ok", "pay_fail"):
             assert got[key][e].tolist() == want[key], "%s env %d: %s vs %s" % (key, e, got[key][e].tolist(), want[key])
-        assert np.allclose(got["rx_power"][e], np.array(want["rx_power"]), rtol=1e-7, atol=0.0)
+        # received power: the device evaluates FSPL with its own log10/pow, so link powers (~0.2 mW at 1 m,
+        # 40 dBm) differ from the host's in the last bits, and so does the residue left in an idle radio after
+        # +p/-p pairs: compare to a few ulps of the LARGEST power, plus 1e-7 relative
+        assert np.allclose(got["rx_power"][e], np.array(want["rx_power"]), rtol=1e-7, atol=1e-13)
         assert int(got["flags"][e]) == 0

@@ -10,10 +10,11 @@ import gymwipe_amd
 
 N = int(os.environ.get("N", 4096))
 SIM = float(os.environ.get("SIM", 1.0))
+MOBILE = bool(int(os.environ.get("MOBILE", "0")))
 for n in (4, 16, 20):
     rng = np.random.default_rng(n)
     delays = rng.uniform(0, 1e-2, (N, n))
-    grid = gymwipe_amd.VecPhyGrid(N, n, delays)
+    grid = gymwipe_amd.VecPhyGrid(N, n, delays, mobile=MOBILE, seed=99)
     grid.runSimulation(0.05)                       # warm-up (also past the start-up transient)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -29,7 +30,7 @@ for n in (4, 16, 20):
     if not os.environ.get("NO_CPU"):
         from oracle import des_model as dm
         t1 = time.perf_counter()
-        dm.scenario_grid(n, delays[0].tolist(), min(SIM, 0.5))
+        (dm.scenario_mobile_grid(n, delays[0].tolist(), min(SIM, 0.5), seed=99) if MOBILE else dm.scenario_grid(n, delays[0].tolist(), min(SIM, 0.5)))
         cpu = time.perf_counter() - t1
         out["cpu_oracle_python_1core_wall_per_sim_s"] = cpu / min(SIM, 0.5)
         out["speedup_vs_python_oracle"] = out["replica_seconds_per_s"] * out["cpu_oracle_python_1core_wall_per_sim_s"]

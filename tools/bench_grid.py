@@ -22,7 +22,7 @@ for n in (4, 16, 20):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ev = grid.get_state("events").astype(np.int64)
-    out = {"workload": "PHY grid, %d devices, %d replicas, %.2f s simulated each (static)" % (n, N, SIM),
+    out = {"workload": "PHY grid, %d devices, %d replicas, %.2f s simulated each (%s)" % (n, N, SIM, "mobile" if MOBILE else "static"),
            "replica_seconds_per_s": N * SIM / wall, "wall_s": wall, "events_total": int(ev.sum()),
            "events_per_s": float(ev.sum()) / (wall * (SIM + 0.05) / SIM), "n_tx_mean": float(grid.get_state("n_tx").mean()),
            "hdr_ok": int(grid.get_state("hdr_ok").sum()), "hdr_fail": int(grid.get_state("hdr_fail").sum()),

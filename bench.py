@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for RCCL; must precede HIP initialisation
     import torch
     import torch.distributed as dist
     import gymwipe_amd
@@ -111,7 +112,6 @@ def main():
     torch.cuda.set_device(local)
     dev_t = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev_t)
 
     N, D, K, W = args.envs, args.devices, args.steps, args.warmup
@@ -234,7 +234,7 @@ def main():
         }
         if roll is not None:
             out["fused_rollout"] = roll
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(D)
         print(json.dumps(out))
     if world > 1:

@@ -123,10 +123,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and not os.environ.get("GW_LIB"):
+        try:                                   # clean checkout: compile the HIP extension in-tree once
+            build(force=True)
+        except Exception as exc:               # no hipcc / compile error: fail loudly, never fall back
+            raise ImportError(
+                "gymwipe_amd: %s is missing and could not be built (%s). Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gymwipe_amd/csrc` (needs hipcc). "
+                "There is no CPU fallback." % (LIB_PATH, exc))
     if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            "gymwipe_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C gymwipe_amd/csrc` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+        raise ImportError("gymwipe_amd: %s is missing. There is no CPU fallback." % LIB_PATH)
     try:
         import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
     except Exception:

@@ -67,10 +67,11 @@ __device__ __forceinline__ bool receive(const StepMath& m, double ber, const TxT
     return m.decodes(err, pay_bits);
 }
 
-__device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value))
+__device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value)), v >= 0
 {
-    int n = 1;
-    while (v >= 10) { v /= 10; ++n; }
+    return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) +
+           (v >= 10000000) + (v >= 100000000) + (v >= 1000000000);
+}
     return n;
 }
 

@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
     const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
     const int mh = c.mac_hdr, pv = c.payload_value;
-    uint32_t mult[DT];
+    uint32_t mult[DT], term[DT];
 #pragma unroll
-    for (int i = 0; i < DT; ++i) mult[i] = (uint32_t)c.mult[i];
+    for (int i = 0; i < DT; ++i) { mult[i] = (uint32_t)c.mult[i]; term[i] = c.term[i]; }
 
     Tally kt = {0, 0, 0, 0, 0};
     uint32_t k_steps = 0, k_bad = 0, fl = 0;
@@ -206,10 +206,17 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
 
         // (2) close the step (A.5 + interpreter feedback); the other senders' queues stay lazy
         if (finish) {
+            // the listeners' noise states: nothing to look up once every one of them is terminal
+            bool all_term = true;
 #pragma unroll
-            for (int i = 0; i < DT; ++i) {
+            for (int i = 0; i < DT; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
                 if (i == d) { len[i] = len_d; tb[i] = tau; }
-                else {
+            if (!all_term) {
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    if (i == d) continue;
                     uint32_t si = s_trans[(uint32_t)((i * R + RRM) * S) + sta[i]];      // heard the announcement
                     for (uint32_t n = 0; n < n_data; ++n) {                              // ... and d's data
                         const uint32_t s2 = s_trans[(uint32_t)((i * R + d) * S) + si];

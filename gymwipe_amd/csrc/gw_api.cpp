@@ -259,6 +259,16 @@ int gw_create(const gw_config* cfg, gw_env** out)
     }
 
     set_fast_paths(*cfg, env->tab, k);
+    for (int j = 0; j < R; ++j) {
+        uint16_t m = 0;
+        for (int s0 = 0; s0 < env->tab.nstates[j]; ++s0) {
+            bool fixed = true;
+            for (int f = 0; f < R && fixed; ++f)
+                if (f != j && env->tab.trans[((size_t)j * R + f) * GW_MAX_NSTATES + s0] != s0) fixed = false;
+            if (fixed) m |= (uint16_t)(1u << s0);
+        }
+        k.term[j] = m;
+    }
 
     GwState& st = env->st;
     st.N = N; st.D = D; st.R = R;

@@ -20,6 +20,7 @@ struct GwDevConst {
     double  hdr_bits;                   // (mac_hdr*8)*coded_factor
     // exact fast paths, each validated on the host at gw_create (gw_fastmath.h); 0 = use the plain form
     uint32_t inv16[GW_MAX_DEVICES];     // ceil(65536 / mult[i])
+    uint16_t term[GW_MAX_RADIOS + 1];   // bit s of term[j]: noise state s of radio j is terminal (no talker changes it)
     double  inv_slot;                   // RN(1/slot)
     double  fmod_limit;                 // fast fmod is used for t < fmod_limit
     double  rcp_data_rate;              // RN(1/data_rate)

@@ -72,8 +72,6 @@ __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 l
     return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) +
            (v >= 10000000) + (v >= 100000000) + (v >= 1000000000);
 }
-    return n;
-}
 
 
 // reductions over the ACTIVE width of a wave (blocks narrower than 64 leave the upper lanes unborn)

@@ -13,6 +13,7 @@ from . import spaces                                   # noqa: F401
 from .plants import VecLinearPlant                       # noqa: F401
 from .grid import VecPhyGrid                            # noqa: F401
 from .envs import (CounterTrafficEnv, VecCounterTrafficEnv, Interpreter,   # noqa: F401
+                   VecInterpreter, VecPayload,
                    make, register, registry)
 
 __version__ = "0.1.0"

@@ -449,6 +449,12 @@ __global__ void ct_received_sfx_kernel(GwState st, int32_t* __restrict__ out)
     out[idx] = ((rvm >> i) & 1u) ? st.cst->payload_value : 0;
 }
 
+__global__ void ct_delivered_sfx_kernel(GwState st, uint32_t* __restrict__ out)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < (uint32_t)st.N) out[e] = st.sa[(size_t)e * 8 + 2];
+}
+
 template <int DT>
 int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
            int32_t* obs, float* reward, uint8_t* done, void* stream)
@@ -490,6 +496,12 @@ int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, vo
 {
     const unsigned grid = (unsigned)((st.N + 255) / 256);
     hipLaunchKernelGGL(ct_reset_sfx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, mask, obs);
+    return ok_or_ehip();
+}
+
+int gw_launch_delivered_sfx(const GwState& st, uint32_t* out, void* stream)
+{
+    hipLaunchKernelGGL(ct_delivered_sfx_kernel, dim3((unsigned)((st.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, st, out);
     return ok_or_ehip();
 }
 

@@ -406,6 +406,16 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
     return GW_OK;
 }
 
+int gw_delivered(gw_env* env, uint32_t* out_dev, void* stream)
+{
+    if (!env || !out_dev) return fail(GW_EINVAL, "env/out is NULL");
+    if (!env->st.sa) return fail(GW_EUNSUPPORTED, "gw_delivered needs the default (suffix) mode");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_delivered_sfx(env->st, out_dev, stream)) return fail(GW_EHIP, "delivered kernel launch failed");
+    return GW_OK;
+}
+
 int gw_received(gw_env* env, int32_t* out_dev, void* stream)
 {
     if (!env || !out_dev) return fail(GW_EINVAL, "env/out is NULL");

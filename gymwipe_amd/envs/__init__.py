@@ -3,7 +3,7 @@ Environment registry with the reference's ids (gymwipe/envs/__init__.py:6-14).
 ``gym`` itself is not a dependency: ``make`` is a minimal stand-alone registry; when a
 ``gym`` package is importable the ids are registered there too.
 """
-from .core import BaseEnv, Interpreter                                   # noqa: F401
+from .core import BaseEnv, Interpreter, VecInterpreter, VecPayload       # noqa: F401
 from .counter_traffic import CounterTrafficEnv, VecCounterTrafficEnv     # noqa: F401
 
 registry = {}

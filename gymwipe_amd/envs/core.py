@@ -79,3 +79,21 @@ class Interpreter(ABC):
 
     def reset(self):
         pass
+
+
+class VecPayload:
+    """What a vectorised ``onPacketReceived`` gets in place of the reference's ``Transmittable`` payload:
+    ``value`` (the payload value, 2 for every CounterTraffic packet -- swapped constructor arguments,
+    counter_traffic.py:57) and ``count`` (int32[N]: how many packets of the assigned sender the RRM
+    decoded in this step; 0 where none arrived)."""
+
+    def __init__(self, value, count):
+        self.value, self.count = value, count
+
+
+class VecInterpreter(Interpreter):
+    """The plug-in point of the reference (envs/core.py:59-159) for N envs at once: same method names,
+    tensors instead of scalars.  Install with ``VecCounterTrafficEnv(..., interpreter=obj)``; per step the
+    env calls ``onFrequencyBandAssignment(duration[N], deviceIndex[N])`` (argument order as the reference's
+    RRM device calls it, networking/devices.py:200), then ``onPacketReceived(senderIndex[N],
+    receiverIndex[N], VecPayload)`` and returns ``getFeedback()`` instead of the fused kernel's outputs."""

@@ -19,7 +19,7 @@ import numpy as np
 
 from .. import _native as nat
 from .. import spaces
-from .core import BaseEnv, Interpreter
+from .core import BaseEnv, Interpreter, VecInterpreter, VecPayload
 
 
 def _torch():
@@ -80,7 +80,7 @@ class VecCounterTrafficEnv(BaseEnv):
 
     def __init__(self, num_envs, num_devices=2, device="cuda:0", positions=None,
                  multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
-                 reuse_outputs=True, explicit_queue=False, counter_bound=None):
+                 reuse_outputs=True, explicit_queue=False, counter_bound=None, interpreter=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -128,7 +128,16 @@ class VecCounterTrafficEnv(BaseEnv):
             self._done = torch.empty(n, dtype=torch.uint8, device=self.device)
         self._reuse = bool(reuse_outputs)
         self._last = (None, None, None)
-        self.interpreter = _DeviceInterpreter(self)
+        self._custom = interpreter
+        if interpreter is not None:                       # a user-supplied Interpreter replaces the fused one
+            if explicit_queue:
+                raise ValueError("custom interpreters need the default queue mode")
+            self._dest = torch.tensor([int(cfg.dest[i]) for i in range(D)], dtype=torch.int64, device=self.device)
+            self._deliv = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            self._deliv_prev = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+            self.interpreter = interpreter
+        else:
+            self.interpreter = _DeviceInterpreter(self)
 
     # -- helpers ------------------------------------------------------------------------------
     def _stream(self):
@@ -172,6 +181,9 @@ class VecCounterTrafficEnv(BaseEnv):
         with torch.cuda.device(self.device):
             nat.check(self._L.gw_reset(self._h, m.data_ptr() if m is not None else None,
                                        obs.data_ptr(), self._stream()))
+        if self._custom is not None:                      # counter_traffic.py:142-144
+            self._custom.reset()
+            return self._custom.getObservation()
         return obs
 
     def _ready(self, t):
@@ -202,8 +214,23 @@ class VecCounterTrafficEnv(BaseEnv):
                                      done.data_ptr(), self._stream())
         if rc:
             nat.check(rc)
+        if self._custom is not None:
+            return self._feed_custom(dev, dur)
         self._last = (obs, rew, done)
         return obs, rew, done, self._info()
+
+    def _feed_custom(self, dev, dur):
+        """Drive a user-supplied VecInterpreter from what the RRM sniffed in this step."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_delivered(self._h, self._deliv.data_ptr(), self._stream()))
+        count = self._deliv - self._deliv_prev
+        self._deliv_prev.copy_(self._deliv)
+        it = self._custom
+        it.onFrequencyBandAssignment(dur * self.ASSIGNMENT_DURATION_FACTOR, dev)    # swapped, networking/devices.py:200
+        it.onPacketReceived(dev, self._dest[dev.long()].to(torch.int32), VecPayload(self.config.payload_value, count))
+        self._last = it.getFeedback()
+        return self._last
 
     def rollout(self, device, duration, out=None):
         """K consecutive steps from pre-staged actions ``int32[K][N]``; one launch per step, no

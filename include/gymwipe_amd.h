@@ -130,6 +130,11 @@ int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
 int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int32_t* duration_dev,
                int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
 
+/* Cumulative number of data packets the RRM has decoded per env since gw_create: uint32[N], device pointer
+ * (default mode).  A custom Interpreter (envs/core.py:59-159) differences this across a step to learn how many
+ * packets of the assigned sender the RRM sniffed (networking/devices.py:163-168). */
+int gw_delivered(gw_env* env, uint32_t* out_dev, void* stream);
+
 /* receivedValues of every env: int32[N][D] (row-major), device pointer. */
 int gw_received(gw_env* env, int32_t* out_dev, void* stream);
 

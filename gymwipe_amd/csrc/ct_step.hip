@@ -1,4 +1,8 @@
-// ct_step.hip -- HIP kernels (gfx950) for the vectorised CounterTrafficEnv.step().
+// ct_step.hip -- the GENERIC step kernel (GW_CFG_EXPLICIT_QUEUE): MAC queues as explicit rings of packet
+// byte sizes, one per (env, sender), as the reference's deque holds them.  It makes no assumption about
+// what the senders enqueue; the default kernel (ct_step_sfx.hip) exploits the structure of counter
+// traffic instead and is ~12x faster.  Kept as the fallback for other traffic and as an independent
+// second implementation the parity tests run against the same oracle.
 //
 // One launch advances all N environments by one env.step().  The reference walks
 // ~90 SimPy events per step through Python objects (counter_traffic.py:146-158 ->

@@ -74,7 +74,8 @@ __device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls
     return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
 }
 
-// NW = 16-byte words of the qb record held in registers (1 for D <= 7); NW == 0: bytes stay in memory
+// DT > 0: compile-time device count, the qb byte record is held in registers (NWC 16-byte words);
+// DT == 0: any device count, the record's bytes are read and written in memory.
 template <int DT>
 __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
                                                          const int32_t* __restrict__ device,

@@ -67,7 +67,8 @@ class VecCounterTrafficEnv(BaseEnv):
             circle of radius 2 m around the RRM with multiplicities 1,3,1,3,....
         device: torch device string or index ('cuda:0').
         positions / multiplicity / dest / rrm_position: optional overrides of the layout.
-        per_env_stats: keep per-env event counters (tests; costs HBM traffic).
+        per_env_stats: explicit-queue mode only -- keep per-env event counters (the default mode always
+            keeps them in its 32-byte counter record).
         explicit_queue: hold the MAC queues as explicit rings of packet sizes (generic, slower)
             instead of the default exact run-length encoding of counter traffic.
         reuse_outputs: return the same output tensors every step (fast path).

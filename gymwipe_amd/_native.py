@@ -20,15 +20,18 @@ OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED, EFIELD = 0, -1, -2, -3, -4, -
 FLAG_CARRY, FLAG_REFEXC, FLAG_TIE, FLAG_BADACT = 1, 2, 4, 8
 CFG_PER_ENV_STATS = 1
 CFG_EXPLICIT_QUEUE = 2
+CFG_NO_COUNTER_TRAFFIC = 4
+CFG_PEER_RECEIVE = 8
+CFG_FLOAT_DURATION = 16
 
 EXPORTS = (
     "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
-    "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_delivered", "gw_get_state",
+    "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_delivered", "gw_enqueue", "gw_get_state",
     "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue",
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
     "gw_plant_state_ptr", "gw_plant_get_state", "gw_now_ptr",
-    "gw_grid_config_default", "gw_grid_create", "gw_grid_destroy", "gw_grid_run", "gw_grid_get_state",
+    "gw_grid_config_default", "gw_grid_create", "gw_grid_destroy", "gw_grid_run", "gw_grid_get_state", "gw_grid_set_position",
 )
 
 
@@ -149,6 +152,7 @@ def lib():
     L.gw_step.argtypes, L.gw_step.restype = [vp, vp, vp, vp, vp, vp, vp], C.c_int
     L.gw_rollout.argtypes, L.gw_rollout.restype = [vp, i32, vp, vp, vp, vp, vp, vp], C.c_int
     L.gw_received.argtypes, L.gw_received.restype = [vp, vp, vp], C.c_int
+    L.gw_enqueue.argtypes, L.gw_enqueue.restype = [vp, i32, vp, vp], C.c_int
     L.gw_delivered.argtypes, L.gw_delivered.restype = [vp, vp, vp], C.c_int
     L.gw_get_state.argtypes, L.gw_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     L.gw_stats_read.argtypes, L.gw_stats_read.restype = [vp, C.POINTER(Stats)], C.c_int
@@ -173,6 +177,7 @@ def lib():
     L.gw_grid_destroy.argtypes, L.gw_grid_destroy.restype = [vp], C.c_int
     L.gw_grid_run.argtypes, L.gw_grid_run.restype = [vp, C.c_double, vp], C.c_int
     L.gw_grid_get_state.argtypes, L.gw_grid_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
+    L.gw_grid_set_position.argtypes, L.gw_grid_set_position.restype = [vp, i32, vp, vp, vp], C.c_int
     if L.gw_abi_version() != ABI_VERSION:
         raise ImportError("gymwipe_amd: ABI mismatch (library %d, python %d); rebuild"
                           % (L.gw_abi_version(), ABI_VERSION))

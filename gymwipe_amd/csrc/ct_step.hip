@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
             // ---- A.1 / A.2: announcement ---------------------------------------------
-            const int L = ndigits(slots);
+            const int L = ndigits(slots) + (c.float_duration ? 2 : 0);   // len(str(10000.0)) == len("10000") + 2
             const double pd_a = m.over_rate((double)(L * 8));
             const TxTimes an = tx_times(m, t_a, hd, pd_a);
             k.tx++;
@@ -141,6 +141,15 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             uint8_t s_r = 0;
             bool s_r_loaded = false;
             uint8_t s_r_old = 0;
+            // receive-mode MAC at the destination (simple_stack.py:443-448): it is idle during d's window (its own
+            // window, the only thing that blocks its phyIn handler, ended a slot before the previous step did)
+            const int j_peer = (c.peer_receive && c.dest[d] != d) ? c.dest[d] : -1;
+            uint8_t s_p = 0, s_p_old = 0;
+            uint32_t n_peer = 0;
+            if (j_peer >= 0) {
+                s_p_old = st.rxs[(int64_t)j_peer * N + e];
+                s_p = st.trans[((int64_t)j_peer * R + RRM) * S + s_p_old];    // it heard the announcement too
+            }
 
             if (granted) {
                 const double total = (double)slots * slot;               // simple_stack.py:400
@@ -177,6 +186,11 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                         rvm |= (1u << d);
                         if (pv == c.counter_bound) dn = 1;
                     }
+                    if (j_peer >= 0) {
+                        s_p = st.trans[((int64_t)j_peer * R + d) * S + s_p];
+                        const double ber_p = st.ber[((int64_t)j_peer * R + d) * S + s_p];
+                        if (receive(m, ber_p, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl)) n_peer++;
+                    }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
                     // ticks are older events than the MAC's resume at t_e: they go first
                     ticks_until(rd, wake_d, ctr_d, x.t_e, true, mult_d, base_bytes, bound, interval, k, fl);
@@ -204,8 +218,12 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             // ---- rx-power state of every radio (simple_stack.py:130-157) ---------------------
             if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
             if (s_r_loaded && s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
+            if (j_peer >= 0) {
+                if (s_p != s_p_old) st.rxs[(int64_t)j_peer * N + e] = s_p;
+                if (n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
+            }
             for (int j = 0; j < D; ++j) {
-                if (j == d) continue;
+                if (j == d || j == j_peer) continue;
                 uint8_t s = st.rxs[(int64_t)j * N + e];
                 const uint8_t s0 = s;
                 s = st.trans[((int64_t)j * R + RRM) * S + s];
@@ -256,7 +274,7 @@ __global__ void ct_init_kernel(GwState st)
     if (e >= N) return;
     const int D = st.cst->D, R = st.cst->R;
     st.now[e] = 0.0;
-    st.wake[e] = 0.0;
+    st.wake[e] = st.cst->no_traffic ? (double)INFINITY : 0.0;
     st.counter[e] = 1u;
     st.rvmask[e] = 0u;
     st.last_abs[e] = 0;
@@ -265,6 +283,28 @@ __global__ void ct_init_kernel(GwState st)
     if (st.qhl) for (int i = 0; i < D; ++i) st.qhl[(int64_t)i * N + e] = 0;
     for (int r = 0; r < R; ++r) st.rxs[(int64_t)r * N + e] = 0;
     if (st.pe_stats) for (int s = 0; s < 5; ++s) st.pe_stats[(int64_t)s * N + e] = 0ull;
+    if (st.peer_rx) for (int i = 0; i < D; ++i) st.peer_rx[(int64_t)i * N + e] = 0u;
+}
+
+// SimpleNetworkDevice.send -> SimpleMac.networkInHandler: one packet appended per env (devices.py:84-86,
+// simple_stack.py:463-471)
+__global__ void ct_enqueue_kernel(GwState st, int sender, const int32_t* __restrict__ payload_bytes)
+{
+    const int64_t N = st.N;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    const int32_t pb = payload_bytes[e];
+    if (pb < 0) return;
+    const GwDevConst& c = *st.cst;
+    const uint16_t hl = st.qhl[(int64_t)sender * N + e];
+    Ring r;
+    r.base = st.ring + (((int64_t)e * c.D + sender) << 7);
+    r.head = hl & 0xff;
+    r.len = hl >> 8;
+    Tally k = {0, 0, 0, 0, 0};
+    tick_append(r, (uint32_t)(c.mac_hdr + c.net_hdr + pb), 1, k);
+    st.qhl[(int64_t)sender * N + e] = (uint16_t)(r.head | (r.len << 8));
+    if (st.pe_stats) { st.pe_stats[2 * N + e] += k.app; st.pe_stats[4 * N + e] += k.drop; }
 }
 
 // counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound
@@ -326,6 +366,13 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
     else
         hipLaunchKernelGGL(ct_step_kernel<false>, dim3(grid), dim3(blk), 0, (hipStream_t)stream,
                            st, device, duration, obs, reward, done);
+    return check_launch();
+}
+
+int gw_launch_enqueue(const GwState& st, int sender, const int32_t* payload_bytes, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + 255) / 256);
+    hipLaunchKernelGGL(ct_enqueue_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, sender, payload_bytes);
     return check_launch();
 }
 

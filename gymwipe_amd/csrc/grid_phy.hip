@@ -391,6 +391,65 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
     }
 }
 
+// Position.set() from the host: the (A)/(B) part of the MOVE handler at the replica's current time
+__global__ __launch_bounds__(64) void grid_set_position_kernel(GwGridDev g, int dev, const double* __restrict__ xs, const double* __restrict__ ys)
+{
+    const int lane = threadIdx.x;
+    const int n = g.n;
+    const int64_t env = blockIdx.x;
+    const bool me = lane < n;
+    extern __shared__ double s_prx[];
+    double* s_px = s_prx + n * n;
+    double* s_py = s_px + n;
+    for (int i = lane; i < n * n; i += 64) s_prx[i] = g.txp[env * n * n + i];
+    GwGridLane L;
+    if (me) L = g.lanes[env * n + lane];
+    else { memset(&L, 0, sizeof L); }
+    const double now = g.envs[env].now;
+    if (me && lane == dev) { L.px = xs[env]; L.py = ys[env]; }
+    if (me) { s_px[lane] = L.px; s_py[lane] = L.py; }
+    __syncthreads();
+    const double br = g.bit_rate;
+    auto power_changed = [&]() {
+        L.err_sum += L.ber * (now - L.t_seg) * br;
+        if (!(now >= L.rx_stop)) {
+            const double sig = s_prx[L.rx_src * n + lane];
+            const double noise = L.rx_power - sig;
+            if (!(noise >= 0)) L.flags |= GW_FLAG_REFEXC;
+            L.ber = ber_bpsk(sig, noise, g.ten_log_br, g.sqrt2pi);
+        }
+    };
+    const unsigned long long on_air = __ballot(me && L.tx_on);
+    if (((on_air >> dev) & 1ull) && me && lane != dev) {
+        const double dx = L.px - s_px[dev], dy = L.py - s_py[dev];
+        if (sqrt(dx * dx + dy * dy) < 3000.0) {
+            const double np_ = fspl_power(L.px, L.py, s_px[dev], s_py[dev], g.tx_power_dbm, g.twenty_log_f);
+            const double delta = np_ - s_prx[dev * n + lane];
+            s_prx[dev * n + lane] = np_;
+            L.rx_power = L.rx_power + delta;
+            if (L.receiving && delta != 0) power_changed();
+        }
+    }
+    if (me && lane == dev) {
+        unsigned long long rest = on_air & ~(1ull << dev);
+        while (rest) {
+            const int i = __ffsll((long long)rest) - 1;
+            rest &= rest - 1;
+            const double dx = L.px - s_px[i], dy = L.py - s_py[i];
+            if (sqrt(dx * dx + dy * dy) < 3000.0) {
+                const double np_ = fspl_power(s_px[i], s_py[i], L.px, L.py, g.tx_power_dbm, g.twenty_log_f);
+                const double delta = np_ - s_prx[i * n + lane];
+                s_prx[i * n + lane] = np_;
+                L.rx_power = L.rx_power + delta;
+                if (L.receiving && delta != 0) power_changed();
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < n * n; i += 64) g.txp[env * n * n + i] = s_prx[i];
+    if (me) g.lanes[env * n + lane] = L;
+}
+
 __global__ void grid_init_kernel(GwGridDev g, const double* __restrict__ delays, const double* __restrict__ pos, double thermal)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,6 +489,13 @@ int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream)
     const size_t lds = ((size_t)g.n * g.n + 2 * (size_t)g.n) * sizeof(double);
     if (g.mobile) hipLaunchKernelGGL(grid_run_kernel<true>, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
     else          hipLaunchKernelGGL(grid_run_kernel<false>, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
+int gw_grid_launch_set_position(const GwGridDev& g, int dev, const double* xs, const double* ys, void* stream)
+{
+    const size_t lds = ((size_t)g.n * g.n + 2 * (size_t)g.n) * sizeof(double);
+    hipLaunchKernelGGL(grid_set_position_kernel, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, dev, xs, ys);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 

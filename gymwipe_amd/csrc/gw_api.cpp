@@ -106,6 +106,8 @@ int validate(const gw_config& c)
             if (c.mult[i] > GW_MAX_MULT)
                 return fail(GW_EUNSUPPORTED, "mult[%d] > %d needs GW_CFG_EXPLICIT_QUEUE", i, GW_MAX_MULT);
     }
+    if ((c.flags & (GW_CFG_NO_COUNTER_TRAFFIC | GW_CFG_PEER_RECEIVE | GW_CFG_FLOAT_DURATION)) && !(c.flags & GW_CFG_EXPLICIT_QUEUE))
+        return fail(GW_EUNSUPPORTED, "GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION need GW_CFG_EXPLICIT_QUEUE");
     if ((int64_t)c.max_duration * c.duration_factor > 100000000)
         return fail(GW_EINVAL, "max_duration*duration_factor too large");
     return GW_OK;
@@ -250,6 +252,10 @@ int gw_create(const gw_config* cfg, gw_env** out)
     k.mac_hdr = cfg->mac_header_bytes; k.net_hdr = cfg->net_header_bytes;
     k.duration_factor = cfg->duration_factor; k.max_duration = cfg->max_duration;
     for (int i = 0; i < D; ++i) { k.mult[i] = cfg->mult[i]; k.inv16[i] = (65536u + (uint32_t)cfg->mult[i] - 1u) / (uint32_t)cfg->mult[i]; }
+    k.no_traffic = (cfg->flags & GW_CFG_NO_COUNTER_TRAFFIC) ? 1 : 0;
+    k.peer_receive = (cfg->flags & GW_CFG_PEER_RECEIVE) ? 1 : 0;
+    k.float_duration = (cfg->flags & GW_CFG_FLOAT_DURATION) ? 1 : 0;
+    for (int i = 0; i < D; ++i) k.dest[i] = cfg->dest[i];
     k.slot = cfg->slot; k.data_rate = env->tab.data_rate; k.bit_rate = cfg->bit_rate;
     k.coded_factor = env->tab.coded_factor; k.max_ber = cfg->max_ber; k.counter_interval = cfg->counter_interval;
     {
@@ -302,6 +308,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
         }
     }
     if (explicit_q) TRY_ALLOC(st.flags, N);
+    if (explicit_q && (cfg->flags & GW_CFG_PEER_RECEIVE)) TRY_ALLOC(st.peer_rx, N * D);
     if (explicit_q && (cfg->flags & GW_CFG_PER_ENV_STATS)) TRY_ALLOC(st.pe_stats, N * 5);
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
     if (explicit_q) TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
@@ -413,6 +420,17 @@ int gw_delivered(gw_env* env, uint32_t* out_dev, void* stream)
     int rc = select_device(env);
     if (rc) return rc;
     if (gw_launch_delivered_sfx(env->st, out_dev, stream)) return fail(GW_EHIP, "delivered kernel launch failed");
+    return GW_OK;
+}
+
+int gw_enqueue(gw_env* env, int32_t sender, const int32_t* payload_bytes_dev, void* stream)
+{
+    if (!env || !payload_bytes_dev) return fail(GW_EINVAL, "env/payload_bytes is NULL");
+    if (!env->st.ring) return fail(GW_EUNSUPPORTED, "gw_enqueue needs GW_CFG_EXPLICIT_QUEUE");
+    if (sender < 0 || sender >= env->st.D) return fail(GW_EINVAL, "sender out of range");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_enqueue(env->st, sender, payload_bytes_dev, stream)) return fail(GW_EHIP, "enqueue kernel launch failed");
     return GW_OK;
 }
 
@@ -732,6 +750,15 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
                 uint32_t* q = o + ((size_t)e * D + i) * GW_QUEUE_CAP;
                 for (int s = 0; s < GW_QUEUE_CAP; ++s) q[s] = s < len ? r[(head + s) & GW_RING_MASK] : 0u;
             }
+        return GW_OK;
+    }
+    if (!strcmp(field, "peer_received")) {
+        if (!st.peer_rx) return fail(GW_EFIELD, "field peer_received needs GW_CFG_PEER_RECEIVE");
+        NEED(N * D, uint32_t);
+        std::vector<uint32_t> p((size_t)N * D);
+        HIP_TRY(hipMemcpy(p.data(), st.peer_rx, p.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t* o = (uint32_t*)dst;
+        for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = p[(size_t)i * N + e];
         return GW_OK;
     }
     if (!strcmp(field, "rx_power")) {

@@ -152,6 +152,24 @@ int gw_grid_run(gw_grid* g, double seconds, void* stream)
     return GW_OK;
 }
 
+int gw_grid_set_position(gw_grid* g, int32_t device, const double* x_host, const double* y_host, void* stream)
+{
+    if (!g || !x_host || !y_host) return gw_set_error(GW_EINVAL, "grid/x/y is NULL");
+    if (!g->cfg.mobile) return gw_set_error(GW_EUNSUPPORTED, "gw_grid_set_position needs cfg.mobile (per-replica geometry)");
+    if (device < 0 || device >= g->dev.n) return gw_set_error(GW_EINVAL, "device out of range");
+    GRID_HIP(hipSetDevice(g->cfg.hip_device), (void)0);
+    const int64_t N = g->dev.N;
+    double* d_xy = nullptr;
+    GRID_HIP(hipMalloc((void**)&d_xy, (size_t)2 * N * sizeof(double)), (void)0);
+    GRID_HIP(hipMemcpy(d_xy, x_host, (size_t)N * sizeof(double), hipMemcpyHostToDevice), (void)hipFree(d_xy));
+    GRID_HIP(hipMemcpy(d_xy + N, y_host, (size_t)N * sizeof(double), hipMemcpyHostToDevice), (void)hipFree(d_xy));
+    const int rc = gw_grid_launch_set_position(g->dev, device, d_xy, d_xy + N, stream);
+    GRID_HIP(hipStreamSynchronize((hipStream_t)stream), (void)hipFree(d_xy));
+    (void)hipFree(d_xy);
+    if (rc) return gw_set_error(GW_EHIP, "grid set_position launch failed");
+    return GW_OK;
+}
+
 int gw_grid_get_state(gw_grid* g, const char* field, void* dst, size_t bytes)
 {
     if (!g || !field || !dst) return gw_set_error(GW_EINVAL, "grid/field/dst is NULL");
@@ -166,6 +184,11 @@ int gw_grid_get_state(gw_grid* g, const char* field, void* dst, size_t bytes)
     if (!strcmp(field, "now")) { NEEDB(N, double); for (int64_t e = 0; e < N; ++e) ((double*)dst)[e] = envs[e].now; return GW_OK; }
     if (!strcmp(field, "events")) { NEEDB(N, uint32_t); for (int64_t e = 0; e < N; ++e) ((uint32_t*)dst)[e] = envs[e].events; return GW_OK; }
     if (!strcmp(field, "n_tx")) { NEEDB(N, uint32_t); for (int64_t e = 0; e < N; ++e) ((uint32_t*)dst)[e] = envs[e].n_tx; return GW_OK; }
+    if (!strcmp(field, "on_air")) {                     // len(frequencyBand.getActiveTransmissions())
+        NEEDB(N, uint32_t);
+        for (int64_t e = 0; e < N; ++e) { uint32_t c = 0; for (int i = 0; i < n; ++i) c += lanes[(size_t)e * n + i].tx_on ? 1u : 0u; ((uint32_t*)dst)[e] = c; }
+        return GW_OK;
+    }
     if (!strcmp(field, "flags")) {
         NEEDB(N, uint32_t);
         for (int64_t e = 0; e < N; ++e) { uint32_t f = 0; for (int i = 0; i < n; ++i) f |= lanes[(size_t)e * n + i].flags; ((uint32_t*)dst)[e] = f; }

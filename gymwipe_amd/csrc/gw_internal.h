@@ -26,6 +26,8 @@ struct GwDevConst {
     double  rcp_data_rate;              // RN(1/data_rate)
     double  cls_limit;                  // decode-certainty classes are valid for t < cls_limit
     int32_t fast_fmod, fast_div, fast_decide, idem_states;
+    int32_t no_traffic, peer_receive, float_duration;   // GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION
+    int32_t dest[GW_MAX_DEVICES];
 };
 
 struct GwBp { uint32_t t0, c0; };        // counting restarts at tick t0 with counter value c0
@@ -58,6 +60,7 @@ struct GwState {
     int32_t*  last_abs;   // [N]        interpreter._lastAbsDifference
     uint8_t*  done;       // [N]        interpreter._done
     uint8_t*  rxs;        // [R][N]     rx-power state index per radio (stands for phy._receivedPower)
+    uint32_t* peer_rx;    // [D][N] or nullptr (GW_CFG_PEER_RECEIVE): packets a receive-mode MAC handed up
     uint32_t* flags;      // [N]        sticky GW_FLAG_* bits
     uint64_t* pe_stats;   // [5][N] or nullptr: n_tx, n_delivered, n_appended, n_popped, n_dropped
     unsigned long long* totals;  // [n_slots][GW_T_COUNT], one 64-B slot per wave of the step launch:
@@ -115,6 +118,7 @@ struct GwGridDev {
     unsigned long long seed;
 };
 int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream);
+int gw_grid_launch_set_position(const GwGridDev& g, int dev, const double* xs, const double* ys, void* stream);
 int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, const double* pos_dev, double thermal, void* stream);
 
 // Host-side link tables (gw_tables.cpp)
@@ -141,6 +145,7 @@ int gw_launch_reset(const GwState& st, const uint8_t* mask, int32_t* obs, void* 
 int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* duration,
                    int32_t* obs, float* reward, uint8_t* done, void* stream);
 int gw_launch_received(const GwState& st, int32_t* out, void* stream);
+int gw_launch_enqueue(const GwState& st, int sender, const int32_t* payload_bytes, void* stream);
 int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
                        int32_t* obs, float* reward, uint8_t* done, void* stream);
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);

@@ -72,6 +72,10 @@ class VecCounterTrafficEnv(BaseEnv):
         explicit_queue: hold the MAC queues as explicit rings of packet sizes (generic, slower)
             instead of the default exact run-length encoding of counter traffic.
         reuse_outputs: return the same output tensors every step (fast path).
+        counter_traffic / peer_receive / float_duration (explicit_queue only): switch the
+            counter processes off so that packets come from enqueue() only; keep every sender MAC in receive
+            mode (get_state("peer_received") counts what it hands up); pass assignment durations as floats
+            like tests/networking/test_stack.py:197 does.
     """
     COUNTER_INTERVAL = 0.001                              # counter_traffic.py:31
     COUNTER_BYTE_LENGTH = 2                               # :33
@@ -81,7 +85,8 @@ class VecCounterTrafficEnv(BaseEnv):
 
     def __init__(self, num_envs, num_devices=2, device="cuda:0", positions=None,
                  multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
-                 reuse_outputs=True, explicit_queue=False, counter_bound=None, interpreter=None):
+                 reuse_outputs=True, explicit_queue=False, counter_bound=None, interpreter=None,
+                 counter_traffic=True, peer_receive=False, float_duration=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -114,6 +119,12 @@ class VecCounterTrafficEnv(BaseEnv):
             cfg.flags |= nat.CFG_PER_ENV_STATS
         if explicit_queue:
             cfg.flags |= nat.CFG_EXPLICIT_QUEUE
+        if not counter_traffic:
+            cfg.flags |= nat.CFG_NO_COUNTER_TRAFFIC
+        if peer_receive:
+            cfg.flags |= nat.CFG_PEER_RECEIVE
+        if float_duration:
+            cfg.flags |= nat.CFG_FLOAT_DURATION
         if counter_bound is not None:          # tests: reach counter saturation quickly
             cfg.counter_bound = int(counter_bound)
             self.COUNTER_BOUND = int(counter_bound)
@@ -277,7 +288,16 @@ class VecCounterTrafficEnv(BaseEnv):
             nat.check(self._L.gw_received(self._h, out.data_ptr(), self._stream()))
         return out
 
+    def enqueue(self, device, payload_bytes):
+        """SimpleNetworkDevice.send(data, dest) on sender `device` of every env (networking/devices.py:84-86):
+        payload_bytes is an int or an int32[N] tensor/array; negative entries enqueue nothing."""
+        torch = _torch()
+        pb = torch.as_tensor(payload_bytes, dtype=torch.int32, device=self.device).expand(self.num_envs).contiguous()
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_enqueue(self._h, int(device), pb.data_ptr(), self._stream()))
+
     _FIELDS = {
+        "peer_received": (np.uint32, lambda D, R: (D,)),
         "now": (np.float64, lambda D, R: ()), "wake": (np.float64, lambda D, R: (D,)),
         "counter": (np.uint32, lambda D, R: (D,)), "qlen": (np.int32, lambda D, R: (D,)),
         "queue": (np.uint32, lambda D, R: (D, nat.QUEUE_CAP)),

@@ -94,6 +94,16 @@ typedef struct gw_config {
 #define GW_CFG_EXPLICIT_QUEUE 2             /* MAC queues as explicit rings of packet sizes (generic, slower);
                                                default: exact suffix encoding of counter traffic, gw_queue.h */
 
+/* The three flags below widen the path towards the callers SURVEY 8f ranks next (receive-mode MACs and
+ * traffic other than counters); they need GW_CFG_EXPLICIT_QUEUE.  Together they replay the reference's
+ * test_simple_mac (tests/networking/test_stack.py:134-235). */
+#define GW_CFG_NO_COUNTER_TRAFFIC 4         /* no counter processes: packets come from gw_enqueue only */
+#define GW_CFG_PEER_RECEIVE   8             /* every sender MAC is kept in receive mode (a RECEIVE command re-issued on
+                                               completion, test_stack.py:176-186): data packets decoded at dest[d]
+                                               while it is idle are handed up and counted ("peer_received") */
+#define GW_CFG_FLOAT_DURATION 16            /* the assignment duration is passed as a float (test_stack.py:197):
+                                               the announcement payload is len(str(float(slots))) bytes */
+
 typedef struct gw_stats {                   /* totals since gw_create, over all envs */
     uint64_t steps;                         /* env-steps executed */
     uint64_t transmissions;                 /* announcements + data packets */
@@ -123,6 +133,11 @@ int gw_reset(gw_env* env, const uint8_t* mask_dev, int32_t* obs_dev, void* strea
 /* one env.step() for all N envs.  device_dev in [0,D), duration_dev in [0,max_duration). */
 int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
             int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+
+/* SimpleNetworkDevice.send(data, dest[sender]) (networking/devices.py:84-86) -> SimpleMac queue append with
+ * drop-oldest (simple_stack.py:463-471), for every env with payload_bytes_dev[e] >= 0 (int32[N]: byte size of
+ * the network payload; headers are added).  GW_CFG_EXPLICIT_QUEUE only. */
+int gw_enqueue(gw_env* env, int32_t sender, const int32_t* payload_bytes_dev, void* stream);
 
 /* K consecutive env.step() calls from pre-staged actions, inputs/outputs laid out [K][N].  In the default
  * mode this is ONE persistent launch per 64 steps (state in registers, lanes free-running through their
@@ -235,7 +250,13 @@ int gw_grid_create(const gw_grid_config* cfg, const double* initial_delays_host,
 int gw_grid_destroy(gw_grid* g);
 /* SimMan.runSimulation(seconds) for every replica */
 int gw_grid_run(gw_grid* g, double seconds, void* stream);
-/* host copies: "now" f64[N] | "events","n_tx","flags" u32[N] | "n_sent","hdr_ok","hdr_fail","pay_ok","pay_fail" u32[N][n]
+/* Position.set(x, y) of device `device` in every replica at the replicas' current time (devices/core.py:77-86):
+ * the attenuation of every link of that device changes and every radio that is hearing a transmission over
+ * such a link updates its received power and re-integrates its bit errors (simple_stack.py:119-128).
+ * x_host / y_host: double[N].  Needs cfg.mobile != 0 (per-replica geometry); set move_interval very large to
+ * have scripted moves only. */
+int gw_grid_set_position(gw_grid* g, int32_t device, const double* x_host, const double* y_host, void* stream);
+/* host copies: "now" f64[N] | "events","n_tx","flags","on_air" u32[N] (on_air = transmissions currently active) | "n_sent","hdr_ok","hdr_fail","pay_ok","pay_fail" u32[N][n]
  *              | "rx_power" f64[N][n] | "pos" f64[N][n][2] */
 int gw_grid_get_state(gw_grid* g, const char* field, void* dst_host, size_t bytes);
 

@@ -801,12 +801,26 @@ def default_multiplicity(num_devices):
 
 
 class _Sender(NetDevice):                   # counter_traffic.py:37-61
-    def __init__(self, world, name, x, y, mult):
+    def __init__(self, world, name, x, y, mult, traffic=True):
         NetDevice.__init__(self, world, name, x, y)
         self.mult = mult
         self.counter = 1
         self.dest = None
-        world.sim.process(self._run())
+        self.got = []                       # payloads handed up by a receive-mode MAC
+        if traffic:
+            world.sim.process(self._run())
+
+    def keep_receiving(self, duration):
+        """The receiver process of tests/networking/test_stack.py:176-186: a
+        RECEIVE command re-issued as soon as the previous one completes."""
+        def loop():
+            while True:
+                cmd = Cmd(self.world.sim, "RECEIVE", duration=duration)
+                self.mac.net_in.trigger(cmd)
+                res = yield cmd.done
+                if res is not None:
+                    self.got.append(res)
+        self.world.sim.process(loop())
 
     def _run(self):
         assert self.dest is not None
@@ -853,7 +867,13 @@ class CounterTrafficModel:
     layout IS the reference env (counter_traffic.py:114-158)."""
 
     def __init__(self, num_devices=2, positions=None, mult=None, dest=None,
-                 rrm_pos=(0.0, 0.0)):
+                 rrm_pos=(0.0, 0.0), traffic=True, peer_receive=False,
+                 rx_duration=10, float_duration=False):
+        """traffic=False: no counter processes, packets come from enqueue();
+        peer_receive: every sender MAC is kept in receive mode (SURVEY 8f rank
+        2; the reference env never does this); float_duration: the assignment
+        duration is passed as a float, as test_stack.py:197 does, which makes
+        the announcement payload len(str(float)) bytes long."""
         D = num_devices
         positions = positions or circle_layout(D)
         mult = mult or default_multiplicity(D)
@@ -861,7 +881,7 @@ class CounterTrafficModel:
         self.world = World()
         self.sim = self.world.sim
         self.senders = [_Sender(self.world, "Sender %d" % (i + 1),
-                                positions[i][0], positions[i][1], mult[i])
+                                positions[i][0], positions[i][1], mult[i], traffic)
                         for i in range(D)]
         idx2mac = {i: s.mac_addr for i, s in enumerate(self.senders)}
         for i, s in enumerate(self.senders):
@@ -869,6 +889,14 @@ class CounterTrafficModel:
         self.interp = _Interp(D)
         self.rrm = RrmDevice(self.world, "RRM", rrm_pos[0], rrm_pos[1], idx2mac, self.interp)
         self.num_devices = D
+        self.float_duration = float_duration
+        if peer_receive:
+            for s in self.senders:
+                s.keep_receiving(rx_duration)
+
+    def enqueue(self, device, nbytes):      # networking/devices.py:84-86
+        s = self.senders[device]
+        s.send(Blob(COUNTER_BYTE_LENGTH, nbytes), s.dest)
 
     def reset(self):                        # counter_traffic.py:135-144
         for s in self.senders:
@@ -878,7 +906,8 @@ class CounterTrafficModel:
 
     def step(self, device, duration):       # counter_traffic.py:146-158
         assert 0 <= device < self.num_devices and 0 <= duration < MAX_ASSIGN_DURATION
-        sig = self.rrm.assign(device, duration * ASSIGNMENT_DURATION_FACTOR)
+        slots = duration * ASSIGNMENT_DURATION_FACTOR
+        sig = self.rrm.assign(device, float(slots) if self.float_duration else slots)
         self.sim.run(sig.done)
         return self.interp.feedback()
 
@@ -891,6 +920,7 @@ class CounterTrafficModel:
             "qlen": [len(s.mac.queue) for s in self.senders],
             "queues": [[p.byte_size for p in s.mac.queue] for s in self.senders],
             "received": list(self.interp.received),
+            "peer_received": [len(s.got) for s in self.senders],
             "rx_power": [r.phy.rx_power for r in radios],
             "n_tx": len(self.world.band.log),
         }

@@ -99,20 +99,20 @@ def test_reference_simple_phy_known_answer_on_the_gpu():
     delays = np.tile(np.array([0.0, 1e9]), (N, 1))           # device 2 never sends
     g = VecPhyGrid(N, 2, delays, positions=[(0.0, 0.0), (1.0, 1.0)], mobile=True, tx_power_dbm=0.0,
                    header_bytes=8, payload_bytes=128, send_interval=0.5, move_interval=1e12)
-    g.run(0.25)
+    g.runSimulation(0.25)
     assert (g.get_state("on_air") == want["idle_before"]).all()
-    g.run(0.25 + 8 / dr)                                     # the SEND command is issued at t = 0.5
+    g.runSimulation(0.25 + 8 / dr)                                     # the SEND command is issued at t = 0.5
     assert (g.get_state("on_air") == want["active_during"]).all()
     before = g.get_state("rx_power")[:, 1].copy()
     np.testing.assert_allclose(before, want["power_before"], rtol=1e-12)
-    g.run(64 / dr)
+    g.runSimulation(64 / dr)
     g.setPosition(1, 2.0, 1.0)
-    g.run(16 / dr)
+    g.runSimulation(16 / dr)
     after = g.get_state("rx_power")[:, 1]
     assert (after < before).all()
     np.testing.assert_allclose(after, want["power_after"], rtol=1e-12)
     np.testing.assert_allclose(g.get_state("pos")[:, 1], [[2.0, 1.0]] * N)
-    g.run(0.2)
+    g.runSimulation(0.2)
     assert (g.get_state("on_air") == want["active_after"]).all()
     assert (g.get_state("hdr_ok")[:, 1] == 1).all() and (g.get_state("pay_ok")[:, 1] == 1).all()
     assert (g.get_state("hdr_fail") == 0).all() and (g.get_state("pay_fail") == 0).all()

@@ -95,8 +95,11 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--devices", type=int, default=4, help="senders per env (D)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL observation gather at N>1")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: also all-gather every step's packed (obs, reward, done) record over RCCL (what a central "
+                         "learner would need).  Off by default: environments are independent, the path has no exchange step")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
+    ap.add_argument("--no-graph", action="store_true", help="skip the secondary hipGraph-replay measurement")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for RCCL; must precede HIP initialisation
@@ -109,10 +112,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # GW_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
+    # host-side collectives); the driver's runs use the default, RCCL with one GPU per rank.
+    backend = os.environ.get("GW_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev_t = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev_t)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev_t)
+        else:
+            dist.init_process_group(backend)
 
     N, D, K, W = args.envs, args.devices, args.steps, args.warmup
     env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, device=dev_t)
@@ -120,7 +131,7 @@ def main():
     # outputs as three views of ONE packed record buffer so that the end-of-step observation
     # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
     from gymwipe_amd.sharding import PipelinedGather, StepRecord
-    pipe = PipelinedGather(N, dev_t, world) if (world > 1 and not args.no_gather) else None
+    pipe = PipelinedGather(N, dev_t, world) if (world > 1 and args.gather and backend == "nccl") else None
     rec = StepRecord(N, dev_t)
     env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
 
@@ -199,7 +210,39 @@ def main():
                 "what": "gw_rollout: one persistent launch per %d pre-staged steps (ct_rollout_sfx.hip), same K steps, "
                         "same outputs; not the headline because env.step() is one call per step" % RESET_EVERY}
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev_t)
+    # ---- secondary: the same K steps as hipGraph replays (reset + 64 gw_step launches captured once) ----------
+    graph_sec = None
+    if not args.no_graph and K % RESET_EVERY == 0 and W % RESET_EVERY == 0:
+        G = RESET_EVERY
+        g_dev = torch.zeros((G, N), dtype=torch.int32, device=dev_t)
+        g_dur = torch.zeros((G, N), dtype=torch.int32, device=dev_t)
+        env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
+        side = torch.cuda.Stream(device=dev_t)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            env.reset()
+            for j in range(G):
+                env.step({"device": g_dev[j], "duration": g_dur[j]})
+
+        def run_graphs():
+            for lo in range(W, W + K, G):
+                g_dev.copy_(a_dev[lo:lo + G])
+                g_dur.copy_(a_dur[lo:lo + G])
+                graph.replay()
+        run_graphs()                                  # warm-up
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        run_graphs()
+        torch.cuda.synchronize()
+        g_wall = time.perf_counter() - t2
+        env.check()
+        graph_sec = {"env_steps_per_s_this_rank": N * K / g_wall, "ms_per_step": g_wall / K * 1e3,
+                     "what": "the same K gw_step launches replayed from a hipGraph of reset + %d steps (launch-bound "
+                             "host loop removed; includes the copy of each chunk's actions into the graph's input buffers)" % G}
+
+    t = torch.tensor([wall], dtype=torch.float64, device=dev_t if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
@@ -218,7 +261,8 @@ def main():
             "config": {"workload": "CounterTrafficEnv, %d devices, %d vectorised envs per GPU, reset every %d steps"
                                    % (D, N, RESET_EVERY),
                        "envs_per_gpu": N, "devices": D, "global_envs": world * N,
-                       "obs_gather": bool(world > 1 and not args.no_gather),
+                       "obs_gather": pipe is not None, "parallelism": "independent env shards, one process per GPU, "
+                                                                      "no data-path collective",
                        "launches_per_step": 1, "stream_ms_per_step": stream_s / K * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": measured_traffic(D, N),
@@ -234,6 +278,8 @@ def main():
         }
         if roll is not None:
             out["fused_rollout"] = roll
+        if graph_sec is not None:
+            out["graph_replay"] = graph_sec
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(D)
         print(json.dumps(out))

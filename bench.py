@@ -90,14 +90,14 @@ def cpu_baseline(D, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=1024)      # 64 warm-up + 1 024 timed steps
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--devices", type=int, default=4, help="senders per env (D)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="N>1: also all-gather every step's packed (obs, reward, done) record over RCCL (what a central "
-                         "learner would need).  Off by default: environments are independent, the path has no exchange step")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N>1: skip the end-of-step observation gather (the only exchange of the path: one byte per "
+                         "env-step, one RCCL all-gather per 64 steps, overlapped with stepping)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the secondary hipGraph-replay measurement")
     args = ap.parse_args()
@@ -130,8 +130,20 @@ def main():
 
     # outputs as three views of ONE packed record buffer so that the end-of-step observation
     # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
-    from gymwipe_amd.sharding import PipelinedGather, StepRecord
-    pipe = PipelinedGather(N, dev_t, world) if (world > 1 and args.gather and backend == "nccl") else None
+    from gymwipe_amd.sharding import ChunkedFeedbackGather, StepRecord
+    pipe = None
+    if world > 1 and not args.no_gather:
+        if backend == "nccl":
+            pipe = ChunkedFeedbackGather(N, dev_t, env.pack_feedback, world, chunk=RESET_EVERY)
+        else:                                                    # rehearsal: pack on the GPU, gather on the host
+            stage = torch.empty((RESET_EVERY, N), dtype=torch.uint8, device=dev_t)
+
+            def pack_to_host(o, r, d, out):
+                env.pack_feedback(o, r, d, stage[:o.shape[0]])
+                out.copy_(stage[:o.shape[0]])
+            pipe = ChunkedFeedbackGather(N, dev_t, pack_to_host, world, chunk=RESET_EVERY)
+            pipe.packed = [torch.zeros((RESET_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
+            pipe.gathered = [torch.zeros((world, RESET_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
     rec = StepRecord(N, dev_t)
     env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
 
@@ -144,12 +156,11 @@ def main():
     def one(i):
         if i % RESET_EVERY == 0:
             env.reset()
-        if pipe is not None:                      # write this step's outputs into the free record
-            r = pipe.current()
-            env._obs, env._rew, env._done = r.obs, r.reward, r.done
+        if pipe is not None:                      # this step's outputs go into the current chunk record
+            env._obs, env._rew, env._done = pipe.slot()
         env.step(acts[i])
         if pipe is not None:
-            pipe.submit()                         # async all-gather over RCCL; overlaps the next step
+            pipe.stepped()                        # every 64th step: pack to bytes + async all-gather over RCCL
 
     for i in range(W):
         one(i)
@@ -242,6 +253,22 @@ def main():
                      "what": "the same K gw_step launches replayed from a hipGraph of reset + %d steps (launch-bound "
                              "host loop removed; includes the copy of each chunk's actions into the graph's input buffers)" % G}
 
+    # ---- secondary: steady state without resets (SURVEY 8d asks for it separately): after ~0.2 s of simulated
+    #      time the packets have outgrown every window and steps carry no data any more --------------------
+    env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
+    n_ss = min(256, K)
+    for i in range(W, W + min(64, K)):
+        env.step(acts[i])
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for i in range(W, W + n_ss):
+        env.step(acts[i])
+    torch.cuda.synchronize()
+    ss_wall = time.perf_counter() - t3
+    steady = {"env_steps_per_s_this_rank": N * n_ss / ss_wall, "ms_per_step": ss_wall / n_ss * 1e3, "steps": n_ss,
+              "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "
+                      "for any window, so a step is the announcement plus counter ticks"}
+
     t = torch.tensor([wall], dtype=torch.float64, device=dev_t if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -261,8 +288,10 @@ def main():
             "config": {"workload": "CounterTrafficEnv, %d devices, %d vectorised envs per GPU, reset every %d steps"
                                    % (D, N, RESET_EVERY),
                        "envs_per_gpu": N, "devices": D, "global_envs": world * N,
-                       "obs_gather": pipe is not None, "parallelism": "independent env shards, one process per GPU, "
-                                                                      "no data-path collective",
+                       "obs_gather": pipe is not None,
+                       "parallelism": "independent env shards, one process per GPU; only exchange: end-of-step feedback "
+                                      "gather, 1 byte per env-step, one RCCL all-gather per %d steps overlapped with stepping"
+                                      % RESET_EVERY,
                        "launches_per_step": 1, "stream_ms_per_step": stream_s / K * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": measured_traffic(D, N),
@@ -280,6 +309,7 @@ def main():
             out["fused_rollout"] = roll
         if graph_sec is not None:
             out["graph_replay"] = graph_sec
+        out["steady_state_no_reset"] = steady
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(D)
         print(json.dumps(out))

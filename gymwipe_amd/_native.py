@@ -26,7 +26,7 @@ CFG_FLOAT_DURATION = 16
 
 EXPORTS = (
     "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
-    "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_delivered", "gw_enqueue", "gw_get_state",
+    "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_received", "gw_delivered", "gw_enqueue", "gw_pack_feedback", "gw_unpack_feedback", "gw_get_state",
     "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue",
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
@@ -153,6 +153,8 @@ def lib():
     L.gw_rollout.argtypes, L.gw_rollout.restype = [vp, i32, vp, vp, vp, vp, vp, vp], C.c_int
     L.gw_received.argtypes, L.gw_received.restype = [vp, vp, vp], C.c_int
     L.gw_enqueue.argtypes, L.gw_enqueue.restype = [vp, i32, vp, vp], C.c_int
+    L.gw_pack_feedback.argtypes, L.gw_pack_feedback.restype = [vp, C.c_int64, vp, vp, vp, vp, i32, vp], C.c_int
+    L.gw_unpack_feedback.argtypes, L.gw_unpack_feedback.restype = [vp, C.c_int64, vp, vp, vp, vp, vp], C.c_int
     L.gw_delivered.argtypes, L.gw_delivered.restype = [vp, vp, vp], C.c_int
     L.gw_get_state.argtypes, L.gw_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     L.gw_stats_read.argtypes, L.gw_stats_read.restype = [vp, C.POINTER(Stats)], C.c_int

@@ -61,6 +61,7 @@ struct gw_env {
     void*        blocks[32];  // every hipMalloc'd block, for gw_destroy
     int          nblocks;
     uint64_t     bytes;
+    uint32_t*    pack_bad;    // device counter: elements gw_pack_feedback could not represent
 };
 
 namespace {
@@ -431,6 +432,42 @@ int gw_enqueue(gw_env* env, int32_t sender, const int32_t* payload_bytes_dev, vo
     int rc = select_device(env);
     if (rc) return rc;
     if (gw_launch_enqueue(env->st, sender, payload_bytes_dev, stream)) return fail(GW_EHIP, "enqueue kernel launch failed");
+    return GW_OK;
+}
+
+int gw_pack_feedback(gw_env* env, int64_t count, const int32_t* obs_dev, const float* reward_dev, const uint8_t* done_dev,
+                     uint8_t* packed_dev, int32_t check, void* stream)
+{
+    if (!env || count < 0) return fail(GW_EINVAL, "env is NULL or count negative");
+    if (count > 0 && (!obs_dev || !reward_dev || !done_dev || !packed_dev)) return fail(GW_EINVAL, "a buffer is NULL");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (!env->pack_bad) {
+        if ((rc = dev_alloc(env, &env->pack_bad, 1))) return rc;
+        HIP_TRY(hipMemset(env->pack_bad, 0, sizeof(uint32_t)));
+    }
+    if (count > 0 && gw_launch_pack_feedback(count, env->cfg.counter_bound, env->cfg.payload_value, obs_dev, reward_dev, done_dev,
+                                             packed_dev, env->pack_bad, stream))
+        return fail(GW_EHIP, "pack kernel launch failed");
+    if (check) {
+        uint32_t bad = 0;
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(hipMemcpy(&bad, env->pack_bad, sizeof bad, hipMemcpyDeviceToHost));
+        if (bad) return fail(GW_EINVAL, "%u element group(s) were not the built-in interpreter's feedback (not representable in one byte)", bad);
+    }
+    return GW_OK;
+}
+
+int gw_unpack_feedback(gw_env* env, int64_t count, const uint8_t* packed_dev, int32_t* obs_dev, float* reward_dev,
+                       uint8_t* done_dev, void* stream)
+{
+    if (!env || count < 0) return fail(GW_EINVAL, "env is NULL or count negative");
+    if (count == 0) return GW_OK;
+    if (!obs_dev || !reward_dev || !done_dev || !packed_dev) return fail(GW_EINVAL, "a buffer is NULL");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_unpack_feedback(count, env->cfg.counter_bound, env->cfg.payload_value, packed_dev, obs_dev, reward_dev, done_dev, stream))
+        return fail(GW_EHIP, "unpack kernel launch failed");
     return GW_OK;
 }
 

@@ -155,4 +155,9 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
 int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream);
 int gw_launch_delivered_sfx(const GwState& st, uint32_t* out, void* stream);
 
+int gw_launch_pack_feedback(int64_t count, int center, int pv, const int32_t* obs, const float* reward, const uint8_t* done,
+                            uint8_t* packed, uint32_t* bad, void* stream);
+int gw_launch_unpack_feedback(int64_t count, int center, int pv, const uint8_t* packed, int32_t* obs, float* reward, uint8_t* done,
+                              void* stream);
+
 #define GW_MAX_MULT        15          // packets per tick supported by the suffix encoding's ceil-div

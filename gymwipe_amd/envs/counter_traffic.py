@@ -288,6 +288,32 @@ class VecCounterTrafficEnv(BaseEnv):
             nat.check(self._L.gw_received(self._h, out.data_ptr(), self._stream()))
         return out
 
+    def pack_feedback(self, obs, reward, done, out=None, check=False):
+        """(obs int32, reward float32, done uint8) tensors of any common shape -> one byte per element
+        (bits 0-1 sign(obs - COUNTER_BOUND) + 1, bits 2-6 reward + 10, bit 7 done).  Lossless for the built-in
+        interpreter; the unit the multi-GPU observation gather moves (sharding.ChunkedFeedbackGather)."""
+        torch = _torch()
+        assert obs.is_contiguous() and reward.is_contiguous() and done.is_contiguous()
+        assert obs.dtype == torch.int32 and reward.dtype == torch.float32 and done.dtype == torch.uint8
+        if out is None:
+            out = torch.empty(obs.shape, dtype=torch.uint8, device=self.device)
+        assert out.is_contiguous() and out.numel() == obs.numel() == reward.numel() == done.numel()
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_pack_feedback(self._h, obs.numel(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(),
+                                               out.data_ptr(), 1 if check else 0, self._stream()))
+        return out
+
+    def unpack_feedback(self, packed, obs=None, reward=None, done=None):
+        torch = _torch()
+        assert packed.is_contiguous() and packed.dtype == torch.uint8
+        obs = torch.empty(packed.shape, dtype=torch.int32, device=self.device) if obs is None else obs
+        reward = torch.empty(packed.shape, dtype=torch.float32, device=self.device) if reward is None else reward
+        done = torch.empty(packed.shape, dtype=torch.uint8, device=self.device) if done is None else done
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_unpack_feedback(self._h, packed.numel(), packed.data_ptr(), obs.data_ptr(),
+                                                 reward.data_ptr(), done.data_ptr(), self._stream()))
+        return obs, reward, done
+
     def enqueue(self, device, payload_bytes):
         """SimpleNetworkDevice.send(data, dest) on sender `device` of every env (networking/devices.py:84-86):
         payload_bytes is an int or an int32[N] tensor/array; negative entries enqueue nothing."""

@@ -1,9 +1,14 @@
 """
 Multi-GPU host logic: environments are independent (the reference runs one env per process),
 so a global batch is cut into contiguous per-rank shards with NO data-path collective.  The
-only exchange the north star asks for is the end-of-step observation gather: every rank's
-packed (obs, reward, done) record all-gathered once per step -- RCCL over xGMI on GPUs
-(backend "nccl"), gloo on CPU in the tests.
+only exchange the north star asks for is the end-of-step observation gather -- RCCL over xGMI
+on GPUs (backend "nccl"), gloo on CPU in the tests.  Two forms:
+
+* ChunkedFeedbackGather (what bench.py runs at N > 1): one byte per env-step, one all-gather per
+  64 steps, overlapped with the next chunk's stepping -- sized for xGMI, where a collective costs
+  tens of microseconds however small it is;
+* ObservationGather / PipelinedGather: the plain per-step form, every rank's (obs, reward, done)
+  record all-gathered once per step.
 
 The record is ONE contiguous byte buffer laid out [obs int32 x N | reward float32 x N |
 done uint8 x N | pad]; the step kernel writes straight into its three views, so the gather
@@ -101,3 +106,72 @@ class ObservationGather:
         parts = [StepRecord.split(rows[r], n) for r in range(self.world)]
         return (torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]),
                 torch.cat([p[2] for p in parts]))
+
+
+class ChunkedFeedbackGather:
+    """The end-of-step observation gather, batched and compressed for xGMI.
+
+    A per-step all-gather of 9*N bytes is latency-bound (tens of microseconds per collective against a
+    7 us step), so the exchange is made coarser and smaller instead: the step kernel writes the outputs
+    of `chunk` consecutive steps into one [chunk][N] record, a streaming kernel packs them to ONE byte per
+    env-step (gw_pack_feedback: lossless for the built-in interpreter), and one all-gather per chunk moves
+    chunk*N bytes per rank while the next chunk is already being stepped (double-buffered; the collective
+    runs on the backend's stream).  Nothing about the environments themselves is exchanged.
+
+    `pack(obs, reward, done, out)` / `unpack(packed, obs, reward, done)` are the byte codec: on a GPU pass
+    `env.pack_feedback` / `env.unpack_feedback` (the HIP kernels behind the C-ABI).
+    """
+
+    def __init__(self, num_envs, device, pack, world_size=None, chunk=64, depth=2):
+        import torch.distributed as dist
+        self._dist = dist
+        self.world = world_size if world_size is not None else dist.get_world_size()
+        n, g = int(num_envs), int(chunk)
+        self.num_envs, self.chunk, self.depth = n, g, depth
+        self._pack = pack
+        mk = lambda dt: [torch.zeros((g, n), dtype=dt, device=device) for _ in range(depth)]
+        self.obs, self.reward, self.done = mk(torch.int32), mk(torch.float32), mk(torch.uint8)
+        self.packed = mk(torch.uint8)
+        self.gathered = [torch.zeros((self.world, g, n), dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.filled = [0] * depth
+        self.k = 0                                   # steps handed out so far
+
+    def slot(self):
+        """(obs, reward, done) views the NEXT step must write into."""
+        b, j = (self.k // self.chunk) % self.depth, self.k % self.chunk
+        if j == 0 and self.pending[b] is not None:   # this buffer's previous gather must have landed
+            self.pending[b].wait()
+            self.pending[b] = None
+        return self.obs[b][j], self.reward[b][j], self.done[b][j]
+
+    def stepped(self):
+        """Call after each step; starts the chunk's pack + all-gather when the chunk is full.
+        Returns the buffer index that was submitted, or None."""
+        b, j = (self.k // self.chunk) % self.depth, self.k % self.chunk
+        self.k += 1
+        if j + 1 < self.chunk:
+            return None
+        return self._submit(b, self.chunk)
+
+    def _submit(self, b, steps):
+        self._pack(self.obs[b][:steps], self.reward[b][:steps], self.done[b][:steps], self.packed[b][:steps])
+        self.filled[b] = steps
+        self.pending[b] = self._dist.all_gather_into_tensor(self.gathered[b].view(-1), self.packed[b].view(-1), async_op=True)
+        return b
+
+    def drain(self):
+        """Flush a partly filled chunk and wait for every gather in flight."""
+        j = self.k % self.chunk
+        if j:
+            b = (self.k // self.chunk) % self.depth
+            self._submit(b, j)
+            self.k += self.chunk - j                 # the next step starts a fresh chunk
+        for b, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[b] = None
+
+    def result(self, b):
+        """Packed feedback of the whole job for the chunk last gathered into buffer b: uint8[world][steps][N]."""
+        return self.gathered[b][:, :self.filled[b]]

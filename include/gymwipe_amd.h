@@ -139,6 +139,16 @@ int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
  * the network payload; headers are added).  GW_CFG_EXPLICIT_QUEUE only. */
 int gw_enqueue(gw_env* env, int32_t sender, const int32_t* payload_bytes_dev, void* stream);
 
+/* One byte per env-step for the end-of-step observation gather of a multi-GPU job: bits 0-1 sign(obs - COUNTER_BOUND) + 1,
+ * bits 2-6 reward + 10, bit 7 done -- lossless for the built-in interpreter (counter_traffic.py:85-112, envs/core.py:142-153),
+ * 9x less xGMI traffic than the (int32, float32, uint8) triple.  `count` elements in any layout (e.g. [steps][N]).
+ * gw_pack_feedback fails with GW_EINVAL (synchronously, it reads a flag back) if a value is not representable, i.e. the
+ * buffers do not hold the built-in interpreter's feedback. */
+int gw_pack_feedback(gw_env* env, int64_t count, const int32_t* obs_dev, const float* reward_dev, const uint8_t* done_dev,
+                     uint8_t* packed_dev, int32_t check, void* stream);
+int gw_unpack_feedback(gw_env* env, int64_t count, const uint8_t* packed_dev, int32_t* obs_dev, float* reward_dev,
+                       uint8_t* done_dev, void* stream);
+
 /* K consecutive env.step() calls from pre-staged actions, inputs/outputs laid out [K][N].  In the default
  * mode this is ONE persistent launch per 64 steps (state in registers, lanes free-running through their
  * own event sequences: ct_rollout_sfx.hip); results are identical to K gw_step calls. */

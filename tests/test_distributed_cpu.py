@@ -98,3 +98,86 @@ def test_step_record_layout():
     assert o.tolist() == [65534, 65535, 65536, 65537, 65538]
     assert r.tolist() == [-2.0, 0.0, 2.0, 0.0, -2.0] and d.tolist() == [0, 1, 0, 0, 1]
     assert o.data_ptr() == rec.buf.data_ptr() and r.data_ptr() == rec.buf.data_ptr() + 20
+
+
+# ---- the chunked, one-byte-per-env-step gather (bench.py's default at N > 1) -------------------------
+def byte_pack(obs, reward, done, out, bound=65536):
+    """Host restatement of gw_pack_feedback's format, for the gloo ranks (the HIP kernel needs a GPU; the
+    GPU tier checks the kernel against this same function)."""
+    sgn = torch.sign(obs - bound).to(torch.int32)
+    out.copy_(((sgn + 1) | ((reward.to(torch.int32) + 10) << 2) | (done.to(torch.int32) << 7)).to(torch.uint8))
+    return out
+
+
+def byte_unpack(packed, bound=65536, pv=2):
+    b = packed.to(torch.int32)
+    return (bound + pv * ((b & 3) - 1)).to(torch.int32), (((b >> 2) & 31) - 10).to(torch.float32), (b >> 7).to(torch.uint8)
+
+
+def _chunk_worker(rank, world, port, total, D, K, chunk, seed, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gymwipe_amd.sharding import ChunkedFeedbackGather, shard_range
+        from oracle.ct_oracle import CtOracle
+        lo, hi = shard_range(total, world, rank)
+        n = hi - lo
+        rng = np.random.default_rng(seed)
+        dev = rng.integers(0, D, (K, total), dtype=np.int32)
+        dur = rng.integers(0, 20, (K, total), dtype=np.int32)
+        shard = CtOracle(n, D)
+        shard.reset()
+        cg = ChunkedFeedbackGather(n, "cpu", byte_pack, world, chunk=chunk)
+        got = []
+
+        def collect(b):
+            cg.pending[b].wait()
+            got.append(cg.result(b).clone())                     # uint8[world][steps][n]
+
+        for k in range(K):
+            obs, rew, done = cg.slot()
+            o, r, d = shard.step(dev[k, lo:hi], dur[k, lo:hi])
+            obs.copy_(torch.from_numpy(o)); rew.copy_(torch.from_numpy(r)); done.copy_(torch.from_numpy(d))
+            b = cg.stepped()
+            if b is not None:
+                collect(b)
+        tail = K % chunk
+        if tail:
+            b = (cg.k // chunk) % cg.depth
+            cg.drain()
+            got.append(cg.result(b).clone())
+        else:
+            cg.drain()
+        if rank == 0:
+            packed = torch.cat(got, dim=1)                       # [world][K][n]
+            assert packed.shape == (world, K, n)
+            o, r, d = byte_unpack(packed)
+            whole = CtOracle(total, D)
+            whole.reset()
+            for k in range(K):
+                wo, wr, wd = whole.step(dev[k], dur[k])
+                assert (o[:, k].reshape(-1).numpy() == wo).all(), k   # rank-major == global env order
+                assert (r[:, k].reshape(-1).numpy() == wr).all() and (d[:, k].reshape(-1).numpy() == wd).all(), k
+        dist.barrier()
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,chunk", [(12, 4), (10, 4), (3, 8)])
+def test_two_rank_chunked_feedback_gather(tmp_path, K, chunk):
+    world, total, D = 2, 64, 4
+    port = _free_port()
+    mp.spawn(_chunk_worker, args=(world, port, total, D, K, chunk, 33, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_feedback_byte_codec_round_trip():
+    obs = torch.tensor([65534, 65536, 65538, 65536], dtype=torch.int32)
+    rew = torch.tensor([-10.0, 0.0, 10.0, 2.0])
+    done = torch.tensor([0, 1, 0, 1], dtype=torch.uint8)
+    out = torch.empty(4, dtype=torch.uint8)
+    o, r, d = byte_unpack(byte_pack(obs, rew, done, out))
+    assert o.tolist() == obs.tolist() and r.tolist() == rew.tolist() and d.tolist() == done.tolist()

@@ -277,3 +277,31 @@ def test_step_is_capturable_in_a_hip_graph():
             assert (outs[j][0].cpu().numpy() == oo).all() and (outs[j][1].cpu().numpy() == orr).all()
             assert (outs[j][2].cpu().numpy() == od).all()
     assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after graph replays")
+
+
+def test_feedback_byte_codec_kernels():
+    """gw_pack_feedback / gw_unpack_feedback against the host codec the gloo tests use, on real step outputs,
+    an odd element count, and a buffer that is NOT the built-in interpreter's feedback (must be refused)."""
+    import torch
+    from test_distributed_cpu import byte_pack, byte_unpack
+    N, D, K = 1000, 4, 7                                    # 7000 elements: not a multiple of 4 per row
+    env, orc = _mk(N, D)
+    dev, dur = action_stream(12, K, N, D)
+    obs = torch.empty((K, N), dtype=torch.int32, device="cuda")
+    rew = torch.empty((K, N), dtype=torch.float32, device="cuda")
+    done = torch.empty((K, N), dtype=torch.uint8, device="cuda")
+    for k in range(K):
+        env._obs, env._rew, env._done = obs[k], rew[k], done[k]
+        env.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+    packed = env.pack_feedback(obs, rew, done, check=True)
+    want = byte_pack(obs.cpu(), rew.cpu(), done.cpu(), torch.empty((K, N), dtype=torch.uint8))
+    assert (packed.cpu() == want).all()
+    o2, r2, d2 = env.unpack_feedback(packed)
+    assert (o2 == obs).all() and (r2 == rew).all() and (d2 == done).all()
+    ho, hr, hd = byte_unpack(packed.cpu())
+    assert (ho == obs.cpu()).all() and (hr == rew.cpu()).all() and (hd == done.cpu()).all()
+    flat = env.pack_feedback(obs.view(-1)[:4001].contiguous(), rew.view(-1)[:4001].contiguous(), done.view(-1)[:4001].contiguous())
+    assert (flat.cpu() == want.view(-1)[:4001]).all()
+    obs[0, 0] = 70000                                        # not -v / 0 / +v around the bound
+    with pytest.raises(Exception):
+        env.pack_feedback(obs, rew, done, check=True)

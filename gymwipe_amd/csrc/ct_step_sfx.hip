@@ -74,6 +74,23 @@ __device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls
     return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
 }
 
+// Step tables ("blob", built by the host at gw_create: gw_api.cpp; byte offsets all multiples of 16).
+// Staged in LDS, because the step's first decisions wait on two dependent lookups in them:
+//   ber  f64[2][D][S]  [0][d][s]: sender d hearing the RRM in NEW state s;  [1][d][s]: the RRM hearing sender d
+//   mi   u32[D][2]     {mult, ceil(65536/mult)} per sender
+//   h1   u8[D][S]      state of sender j after the announcement:            trans[j][RRM][s0]
+//   r1   u8[D][S]      state of the RRM after one packet of sender d:       trans[RRM][d][s0]
+//   cls  u8[2][D][S]   decode certainty, same indexing as ber
+// Read straight from HBM/L2 (issued before the window loop, consumed after it, so the latency is hidden):
+//   h2   u8[D][D][S]   state of sender j after the announcement AND >= 1 data packet of d (valid when hearing the
+//                      same talker twice changes nothing more, which gw_create verifies: idem_states)
+
+// Keep a wave-uniform constant in registers from here on: without this the compiler re-loads kernel
+// arguments (s_load + s_waitcnt) at a dozen points of the step, each exposing the scalar-cache latency;
+// pinned right after the state loads are issued, all of it hides under the HBM latency of those loads.
+#define PIN_V(x) asm volatile("" : "+v"(x))
+#define PIN_S(x) asm volatile("" : "+s"(x))
+
 // DT > 0: compile-time device count, the qb byte record is held in registers (NWC 16-byte words);
 // DT == 0: any device count, the record's bytes are read and written in memory.
 template <int DT>
@@ -93,24 +110,27 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     constexpr int S = GW_MAX_NSTATES;
     const uint32_t RB = PACKED ? 16u * NWC : (uint32_t)st.RB;
 
-    // ---- lookup tables -> LDS (a few hundred bytes for D = 4).  Their global loads are issued FIRST,
-    //      the per-env state loads right behind them, and only then are the tables written to LDS,
-    //      so that both HBM/L2 latencies overlap (vmcnt is in-order: waiting for the older table
-    //      loads does not wait for the younger state loads).
+    // ---- step tables -> LDS.  Their global loads are issued FIRST, the per-env state loads right behind
+    //      them, and only then are the tables written to LDS, so that both HBM/L2 latencies overlap
+    //      (vmcnt is in-order: waiting for the older table loads does not wait for the younger state loads).
     STAMP(0);
     constexpr int DM = DT > 0 ? DT : GW_MAX_DEVICES;
-    constexpr int TRANS_B = ((DM + 1) * (DM + 1) * S + 15) / 16 * 16;
-    __shared__ __attribute__((aligned(16))) uint8_t s_trans[TRANS_B];
-    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DM * S];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DM * S];
-    const int n_tr = (R * R * S + 15) >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;   // 16-B chunks
+    constexpr GwBlobLayout LM(DM);
+    const GwBlobLayout L(D);
+    __shared__ __attribute__((aligned(16))) uint8_t s_blob[LM.lds_total];
+    const int n_ch = L.lds_total >> 4;                   // 16-byte chunks
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const bool one_pass = DT > 0 && DT <= 7 && nthr >= 64;   // every table fits one chunk per thread
-    uint4 r_tr = make_uint4(0u, 0u, 0u, 0u), r_be = r_tr, r_cl = r_tr;
+    constexpr int PER_FULL = ((LM.lds_total >> 4) + 63) / 64;            // chunks per thread in a 64-thread block
+    constexpr int PER = (DT > 0 && PER_FULL <= 8) ? PER_FULL : 1;
+    const bool one_pass = DT > 0 && PER_FULL <= 8 && nthr >= 64;
+    uint4 r_ch[PER];
     if (one_pass) {
-        if (tid < n_tr) r_tr = ld<uint4>(st.trans, (uint32_t)tid << 4);
-        if (tid < n_be) r_be = ld<uint4>(st.ber2, (uint32_t)tid << 4);
-        if (tid < n_cl) r_cl = ld<uint4>(st.cls2, (uint32_t)tid << 4);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int ch = tid + i * nthr;
+            r_ch[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (ch < n_ch) r_ch[i] = ld<uint4>(st.blob, (uint32_t)ch << 4);
+        }
     }
 
     Tally k = {0, 0, 0, 0, 0};
@@ -146,18 +166,37 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         sa1 = ld<uint4>(st.sa, o32 + 16u);
     }
 
+    // ---- constants -> registers, under the shadow of the loads above --------------------------------
+    StepMath m(c);
+    double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
+    double coded_factor = c.coded_factor, cls_limit = c.cls_limit;
+    int pv = c.payload_value, cbound = c.counter_bound, max_duration = c.max_duration, dfactor = c.duration_factor;
+    int mh = c.mac_hdr, base_b = c.mac_hdr + c.net_hdr, idem_i = c.idem_states;
+    __builtin_amdgcn_sched_barrier(0);
+    PIN_V(m.slot); PIN_V(m.inv_slot); PIN_V(m.fmod_limit); PIN_V(m.dr); PIN_V(m.rcp_dr); PIN_V(m.max_ber);
+    PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide);
+    PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit);
+    PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i);
+    __builtin_amdgcn_sched_barrier(0);
+
     if (one_pass) {
-        if (tid < n_tr) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)tid << 4)) = r_tr;
-        if (tid < n_be) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)tid << 4)) = r_be;
-        if (tid < n_cl) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)tid << 4)) = r_cl;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int ch = tid + i * nthr;
+            if (ch < n_ch) *reinterpret_cast<uint4*>(s_blob + ((uint32_t)ch << 4)) = r_ch[i];
+        }
     } else {
-        for (int i = tid; i < n_tr; i += nthr) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)i << 4)) = ld<uint4>(st.trans, (uint32_t)i << 4);
-        for (int i = tid; i < n_be; i += nthr) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)i << 4)) = ld<uint4>(st.ber2, (uint32_t)i << 4);
-        for (int i = tid; i < n_cl; i += nthr) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)i << 4)) = ld<uint4>(st.cls2, (uint32_t)i << 4);
+        for (int i = tid; i < n_ch; i += nthr) *reinterpret_cast<uint4*>(s_blob + ((uint32_t)i << 4)) = ld<uint4>(st.blob, (uint32_t)i << 4);
     }
     STAMP(1);
     __syncthreads();
     STAMP(2);
+    const double* s_ber = reinterpret_cast<const double*>(s_blob + L.ber);
+    const uint2* s_mi = reinterpret_cast<const uint2*>(s_blob + L.mi);
+    const uint8_t* s_h1 = s_blob + L.h1;
+    const uint8_t* s_rr = s_blob + L.r1;
+    const uint8_t* g_h2 = st.blob + L.h2;               // HBM/L2
+    const uint8_t* s_cls = s_blob + L.cls;
 
     if (live) {
         uint32_t rvm = ip.z;
@@ -165,27 +204,21 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         STAMP(3);
         int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
         uint32_t dn = ip.w >> 31;
-        const int pv = c.payload_value;
         uint32_t fl = 0;
 
-        if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
+        if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)max_duration) {
             // counter_traffic.py:147 asserts; a batched step cannot raise per env: flag + skip
             fl = GW_FLAG_BADACT;
             k_bad = 1;
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
-            obs[e] = latest + c.counter_bound;
+            obs[e] = latest + cbound;
             reward[e] = 0.0f;
             done[e] = (uint8_t)dn;
         } else {
             k_steps = 1;
-            const StepMath m(c);
-            const double slot = c.slot, br = c.bit_rate;
-            const double hd = c.hdr_dur, hdr_bits = c.hdr_bits;
-            const double interval = c.counter_interval;
-            const uint32_t bound = (uint32_t)c.counter_bound;
-            const uint32_t base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
-            const int mh = c.mac_hdr;
-            const bool idem = c.idem_states != 0;
+            const uint32_t bound = (uint32_t)cbound;
+            const uint32_t base_bytes = (uint32_t)base_b;
+            const bool idem = idem_i != 0;
 
             uint32_t len_d, s_d_old, s_r_old;
             if (PACKED) {
@@ -210,27 +243,41 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             bpp.t0 = ip.x; bpp.c0 = ip.y;
             const GwBp* hist = st.bph + ((size_t)e << 7);
             // what the addressed sender / the RRM become after hearing the RRM / sender d once
-            const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];
+            const uint32_t s_d = s_h1[(uint32_t)(d * S) + s_d_old];
+            const uint32_t s_r1 = s_rr[(uint32_t)(d * S) + s_r_old];
+            const uint2 mi = s_mi[d];
+            // ... and every other sender j: after the announcement (n1), and after >= 1 data packet of d too (n2)
+            uint32_t nb[PACKED ? 16 * NWC : 1];
+            uint32_t n1[PACKED ? DT : 1], n2[PACKED ? DT : 1], mlt[PACKED ? DT : 1];
+            if (PACKED) {
+#pragma unroll
+                for (int b = 0; b < 16 * NWC; ++b) nb[b] = (word_of(qw[b >> 4], (b >> 2) & 3) >> ((b & 3) * 8)) & 0xffu;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    n1[i] = s_h1[(uint32_t)(i * S) + nb[DT + i]];
+                    n2[i] = g_h2[(uint32_t)((i * DT + d) * S) + nb[DT + i]];
+                    mlt[i] = s_mi[i].x;
+                }
+            }
             const double ber_a = s_ber[(uint32_t)(d * S) + s_d];
             const uint32_t cls_a = s_cls[(uint32_t)(d * S) + s_d];
-            const uint32_t s_r1 = s_trans[(uint32_t)((RRM * R + d) * S) + s_r_old];
             const double ber_x1 = s_ber[(uint32_t)((D + d) * S) + s_r1];
             const uint32_t cls_x1 = s_cls[(uint32_t)((D + d) * S) + s_r1];
             uint32_t s_r = s_r_old;
-            const uint32_t mult_d = (uint32_t)c.mult[d];
-            const uint32_t inv16_d = c.inv16[d];
-            const bool cls_valid = t_a < c.cls_limit;
+            const uint32_t mult_d = mi.x;
+            const uint32_t inv16_d = mi.y;
+            const bool cls_valid = t_a < cls_limit;
 
             STAMP(4);
-            const int slots = du * c.duration_factor;                     // counter_traffic.py:149
+            const int slots = du * dfactor;                               // counter_traffic.py:149
 
             // ---- A.1 / A.2: announcement ------------------------------------------------------
-            const int L = ndigits(slots);
-            const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(L * 8)));
+            const int Ld = ndigits(slots);
+            const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(Ld * 8)));
             k.tx++;
             STAMP(5);
             const bool granted = decode(m, cls_a, cls_valid, ber_a, an, br, hdr_bits,
-                                        (double)(L * 8) * c.coded_factor, fl);
+                                        (double)(Ld * 8) * coded_factor, fl);
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
@@ -289,17 +336,17 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                     uint32_t cls_x = cls_x1;
                     if (idem) {
                         s_r = s_r1;
-                    } else {
-                        s_r = s_trans[(uint32_t)((RRM * R + d) * S) + s_r];
-                        ber_x = s_ber[(uint32_t)((D + d) * S) + s_r];
-                        cls_x = s_cls[(uint32_t)((D + d) * S) + s_r];
+                    } else {                                              // not seen with f64 link powers; full tables in HBM
+                        s_r = st.trans[(uint32_t)((RRM * R + d) * S) + s_r];
+                        ber_x = st.ber[(uint32_t)((RRM * R + d) * S) + s_r];
+                        cls_x = st.cls[(uint32_t)((RRM * R + d) * S) + s_r];
                     }
                     const bool ok = decode(m, cls_x, cls_valid, ber_x, x, br, hdr_bits,
-                                           (double)(pay * 8) * c.coded_factor, fl);
+                                           (double)(pay * 8) * coded_factor, fl);
                     if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
                         k.deliv++;
                         rvm |= (1u << d);
-                        if (pv == c.counter_bound) dn = 1u;
+                        if (pv == cbound) dn = 1u;
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
                     ticks_to(x.t_e, true);                                // ticks are older events than the MAC's resume
@@ -318,24 +365,18 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 
             // ---- every other sender saw the same n_ticks ticks; every other radio heard the
             //      announcement and, if any, d's data (simple_stack.py:130-157) ------------------
-            auto heard = [&](int j, uint32_t s0) {
-                uint32_t s = s_trans[(uint32_t)((j * R + RRM) * S) + s0];
-                for (int n = 0; n < n_data; ++n) {
-                    const uint32_t s2 = s_trans[(uint32_t)((j * R + d) * S) + s];
-                    if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
-                    s = s2;
-                }
+            auto heard_slow = [&](int j, uint32_t s0) {                   // exact count of hearings, tables in HBM
+                uint32_t s = st.trans[(uint32_t)((j * R + RRM) * S) + s0];
+                for (int n = 0; n < n_data; ++n) s = st.trans[(uint32_t)((j * R + d) * S) + s];
                 return s;
             };
             if (PACKED) {
-                uint32_t nb[16 * NWC];
-#pragma unroll
-                for (int b = 0; b < 16 * NWC; ++b) nb[b] = (word_of(qw[b >> 4], (b >> 2) & 3) >> ((b & 3) * 8)) & 0xffu;
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
                     Tally ki = {0, 0, 0, 0, 0};
-                    const uint32_t li = gw_len_after_ticks(nb[i], n_ticks, (uint32_t)c.mult[i], ki);
-                    const uint32_t si = heard(i, nb[DT + i]);             // LDS lookups
+                    const uint32_t li = gw_len_after_ticks(nb[i], n_ticks, mlt[i], ki);
+                    uint32_t si = n_data ? n2[i] : n1[i];
+                    if (!idem) si = heard_slow(i, nb[DT + i]);
                     if (i != d) { k.app += ki.app; k.drop += ki.drop; }   // d's own ticks were counted in the window
                     nb[i] = (i == d) ? len_d : li;
                     nb[DT + i] = (i == d) ? s_d : si;
@@ -358,8 +399,9 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                     if (i == d) continue;
                     const uint32_t l0 = st.qb[oq + (uint32_t)i];
                     const uint32_t s0 = st.qb[oq + (uint32_t)(D + i)];
-                    const uint32_t s1 = heard(i, s0);
-                    st.qb[oq + (uint32_t)i] = (uint8_t)gw_len_after_ticks(l0, n_ticks, (uint32_t)c.mult[i], k);
+                    const uint32_t s1 = !idem ? heard_slow(i, s0)
+                                              : (n_data ? g_h2[(uint32_t)((i * D + d) * S) + s0] : s_h1[(uint32_t)(i * S) + s0]);
+                    st.qb[oq + (uint32_t)i] = (uint8_t)gw_len_after_ticks(l0, n_ticks, s_mi[i].x, k);
                     if (s1 != s0) st.qb[oq + (uint32_t)(D + i)] = (uint8_t)s1;
                 }
                 st.qb[oq + (uint32_t)d] = (uint8_t)len_d;
@@ -374,7 +416,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             int32_t r = last_abs - abs_d;
             last_abs = abs_d;
             r = r > 10 ? 10 : (r < -10 ? -10 : r);
-            obs[e] = latest + c.counter_bound;
+            obs[e] = latest + cbound;
             reward[e] = (float)r;
             done[e] = (uint8_t)dn;
 

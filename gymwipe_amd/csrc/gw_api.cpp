@@ -288,7 +288,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
 #define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
     const bool explicit_q = (cfg->flags & GW_CFG_EXPLICIT_QUEUE) != 0;
-    uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr;
+    uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr; uint8_t* d_blob = nullptr;
     if (explicit_q) {
         TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
         TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
@@ -318,8 +318,9 @@ int gw_create(const gw_config* cfg, gw_env** out)
 #endif
     TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount + 16);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
     TRY_ALLOC(d_ber2, 2 * D * GW_MAX_NSTATES + 2);  TRY_ALLOC(d_cls2, 2 * D * GW_MAX_NSTATES + 16);
+    TRY_ALLOC(d_blob, GwBlobLayout(D).total + 16);
 #undef TRY_ALLOC
-    st.cst = d_cst; st.trans = d_trans; st.ber = d_ber; st.cls = d_cls; st.ber2 = d_ber2; st.cls2 = d_cls2;
+    st.cst = d_cst; st.trans = d_trans; st.ber = d_ber; st.cls = d_cls; st.ber2 = d_ber2; st.cls2 = d_cls2; st.blob = d_blob;
 
 #define HIP_TRY_D(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rc = fail(GW_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); gw_destroy(env); return rc; } } while (0)
     HIP_TRY_D(hipMemcpy(d_cst, &k, sizeof k, hipMemcpyHostToDevice));
@@ -340,6 +341,25 @@ int gw_create(const gw_config* cfg, gw_env** out)
             }
         HIP_TRY_D(hipMemcpy(d_ber2, b2.data(), b2.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY_D(hipMemcpy(d_cls2, c2.data(), c2.size(), hipMemcpyHostToDevice));
+        // the default step kernel's tables in one block (GwBlobLayout)
+        const GwBlobLayout L(D);
+        std::vector<uint8_t> blob((size_t)L.total, 0);
+        memcpy(blob.data() + L.ber, b2.data(), b2.size() * sizeof(double));
+        memcpy(blob.data() + L.cls, c2.data(), c2.size());
+        const uint8_t* tr = env->tab.trans;
+        const int S = GW_MAX_NSTATES;
+        for (int j = 0; j < D; ++j) {
+            const uint32_t mi[2] = {(uint32_t)k.mult[j], k.inv16[j]};
+            memcpy(blob.data() + L.mi + (size_t)j * 8, mi, 8);
+            for (int s0 = 0; s0 < S; ++s0) {
+                const uint8_t a = tr[((size_t)j * R + D) * S + s0];                 // j hears the RRM
+                blob[(size_t)L.h1 + (size_t)j * S + s0] = a;
+                blob[(size_t)L.r1 + (size_t)j * S + s0] = tr[((size_t)D * R + j) * S + s0];   // the RRM hears j
+                for (int dd = 0; dd < D; ++dd)
+                    blob[(size_t)L.h2 + ((size_t)j * D + dd) * S + s0] = (j == dd) ? a : tr[((size_t)j * R + dd) * S + a];
+            }
+        }
+        HIP_TRY_D(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
     if (st.totals) HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));

@@ -75,6 +75,19 @@ struct GwState {
     //   [0][d][s]: sender d hearing the RRM's announcement;  [1][d][s]: the RRM hearing sender d
     const double*     ber2;      // [2][D][S]
     const uint8_t*    cls2;      // [2][D][S]
+    const uint8_t*    blob;      // GwBlobLayout: the default step kernel's tables in one block
+};
+
+// byte offsets inside GwState::blob (the default step kernel's tables; see ct_step_sfx.hip)
+struct GwBlobLayout {
+    int ber, mi, h1, r1, cls, lds_total, h2, total;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    constexpr explicit GwBlobLayout(int D)
+        : ber(0), mi(2 * D * GW_MAX_NSTATES * 8), h1(mi + (D * 8 + 15) / 16 * 16), r1(h1 + D * GW_MAX_NSTATES),
+          cls(r1 + D * GW_MAX_NSTATES), lds_total(cls + 2 * D * GW_MAX_NSTATES), h2(lds_total),
+          total(h2 + D * D * GW_MAX_NSTATES) {}
 };
 
 // decode certainty of a link in a given noise state (host: gw_tables.cpp; valid while t < fmod_limit)

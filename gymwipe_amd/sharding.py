@@ -136,6 +136,8 @@ class ChunkedFeedbackGather:
         self.pending = [None] * depth
         self.filled = [0] * depth
         self.k = 0                                   # steps handed out so far
+        # the per-step views, made once: slot() is on the host's critical path (one call per 7 us step)
+        self._views = [[(self.obs[b][j], self.reward[b][j], self.done[b][j]) for j in range(g)] for b in range(depth)]
 
     def slot(self):
         """(obs, reward, done) views the NEXT step must write into."""
@@ -143,7 +145,7 @@ class ChunkedFeedbackGather:
         if j == 0 and self.pending[b] is not None:   # this buffer's previous gather must have landed
             self.pending[b].wait()
             self.pending[b] = None
-        return self.obs[b][j], self.reward[b][j], self.done[b][j]
+        return self._views[b][j]
 
     def stepped(self):
         """Call after each step; starts the chunk's pack + all-gather when the chunk is full.

@@ -100,6 +100,7 @@ def main():
                          "env-step, one RCCL all-gather per 64 steps, overlapped with stepping)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the secondary hipGraph-replay measurement")
+    ap.add_argument("--no-steady", action="store_true", help="skip the secondary no-reset steady-state measurement")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for RCCL; must precede HIP initialisation
@@ -255,19 +256,21 @@ def main():
 
     # ---- secondary: steady state without resets (SURVEY 8d asks for it separately): after ~0.2 s of simulated
     #      time the packets have outgrown every window and steps carry no data any more --------------------
-    env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
-    n_ss = min(256, K)
-    for i in range(W, W + min(64, K)):
-        env.step(acts[i])
-    torch.cuda.synchronize()
-    t3 = time.perf_counter()
-    for i in range(W, W + n_ss):
-        env.step(acts[i])
-    torch.cuda.synchronize()
-    ss_wall = time.perf_counter() - t3
-    steady = {"env_steps_per_s_this_rank": N * n_ss / ss_wall, "ms_per_step": ss_wall / n_ss * 1e3, "steps": n_ss,
-              "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "
-                      "for any window, so a step is the announcement plus counter ticks"}
+    steady = None
+    if not args.no_steady:
+        env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
+        n_ss = min(256, K)
+        for i in range(W, W + min(64, K)):
+            env.step(acts[i])
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for i in range(W, W + n_ss):
+            env.step(acts[i])
+        torch.cuda.synchronize()
+        ss_wall = time.perf_counter() - t3
+        steady = {"env_steps_per_s_this_rank": N * n_ss / ss_wall, "ms_per_step": ss_wall / n_ss * 1e3, "steps": n_ss,
+                  "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "
+                          "for any window, so a step is the announcement plus counter ticks"}
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev_t if backend == "nccl" else "cpu")
     if world > 1:
@@ -309,7 +312,8 @@ def main():
             out["fused_rollout"] = roll
         if graph_sec is not None:
             out["graph_replay"] = graph_sec
-        out["steady_state_no_reset"] = steady
+        if steady is not None:
+            out["steady_state_no_reset"] = steady
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(D)
         print(json.dumps(out))

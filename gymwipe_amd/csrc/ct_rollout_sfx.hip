@@ -44,47 +44,113 @@ __device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls
     return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
 }
 
-// actions [K][N] int32 x 2  ->  [N][Kp] u16, Kp = K rounded up to 8 (one 16-byte load = 8 steps)
-__global__ void pack_actions_kernel(uint32_t N, int K, int Kp, const int32_t* __restrict__ device,
-                                    const int32_t* __restrict__ duration, uint16_t* __restrict__ packed)
+// The rollout kernel wants each env's actions and feedback contiguous ([N][Kp]: one 16-byte load = 8 steps of
+// actions, one dword store = 4 steps of feedback); the C-ABI takes and returns step-major arrays ([K][N]).  Both
+// transposes go through an LDS tile of 64 envs x 64 steps so that every global access is a coalesced 16-byte
+// (or, for `done`, 4-byte) access.  Pure streaming kernels, ~42 MB per 64 steps x 65 536 envs each.
+constexpr int TP_ENVS = 64, TP_STEPS = 64;
+
+// actions [K][N] int32 x 2  ->  [N][Kp] u16 (device | duration << 8; 0xffff = invalid or beyond K)
+__global__ __launch_bounds__(256) void pack_actions_kernel(uint32_t N, int K, int Kp, const int32_t* __restrict__ device,
+                                                           const int32_t* __restrict__ duration, uint16_t* __restrict__ packed)
 {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    for (int k0 = 0; k0 < Kp; k0 += 8) {
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
+    __shared__ __attribute__((aligned(16))) uint16_t tile[TP_ENVS][TP_STEPS + 2];                  // +2: rows start on different banks
+    const uint32_t e0 = blockIdx.x * TP_ENVS;
+    const int t = threadIdx.x;
+    const bool vec_ok = (N & 3u) == 0;                                // rows of [K][N] stay 16-byte aligned
+    for (int k0 = 0; k0 < Kp; k0 += TP_STEPS) {
+        // load: thread -> (row r of 16, 4 consecutive envs)
+        const int c4 = (t & 15) * 4, r = t >> 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
-            uint32_t v = 0xffffu;                                    // beyond K: never consumed
+        for (int pass = 0; pass < TP_STEPS / 16; ++pass) {
+            const int kk = pass * 16 + r, k = k0 + kk;
+            uint32_t v[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
             if (k < K) {
-                const int32_t dv = device[(size_t)k * N + e], du = duration[(size_t)k * N + e];
-                // anything outside a byte is invalid for every configuration (D <= 32, max_duration checked below)
-                v = ((uint32_t)dv > 0xfeu || (uint32_t)du > 0xfeu) ? 0xffffu : ((uint32_t)dv | ((uint32_t)du << 8));
+                int32_t dv[4], du[4];
+                const uint32_t e = e0 + (uint32_t)c4;
+                if (vec_ok && e + 3 < N) {
+                    const int4 a = *reinterpret_cast<const int4*>(device + (size_t)k * N + e);
+                    const int4 b = *reinterpret_cast<const int4*>(duration + (size_t)k * N + e);
+                    dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w;
+                    du[0] = b.x; du[1] = b.y; du[2] = b.z; du[3] = b.w;
+                } else {
+                    for (int j = 0; j < 4; ++j) {
+                        const bool in = e + j < N;
+                        dv[j] = in ? device[(size_t)k * N + e + j] : -1;
+                        du[j] = in ? duration[(size_t)k * N + e + j] : -1;
+                    }
+                }
+                // anything outside a byte is invalid for every configuration (D <= 32, max_duration checked by the caller)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = ((uint32_t)dv[j] > 0xfeu || (uint32_t)du[j] > 0xfeu) ? 0xffffu : ((uint32_t)dv[j] | ((uint32_t)du[j] << 8));
             }
-            w[j >> 1] |= v << ((j & 1) * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[c4 + j][kk] = (uint16_t)v[j];
         }
-        *reinterpret_cast<uint4*>(packed + (size_t)e * Kp + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+        __syncthreads();
+        // store: thread -> (env row, 8 consecutive steps = 16 bytes); 8 threads cover one env's 64 steps
+        const int cols = (Kp - k0) < TP_STEPS ? (Kp - k0) : TP_STEPS;   // multiple of 16
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int env = pass * 32 + (t >> 3), s0 = (t & 7) * 8;
+            if (e0 + env < N && s0 < cols) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[env][s0 + 2 * j] | ((uint32_t)tile[env][s0 + 2 * j + 1] << 16);
+                *reinterpret_cast<uint4*>(packed + (size_t)(e0 + env) * Kp + k0 + s0) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        __syncthreads();
     }
 }
 
 // feedback u8[N][Kp] -> obs/reward/done [K][N]
-__global__ void expand_feedback_kernel(uint32_t N, int K, int Kp, int center, int pv, const uint8_t* __restrict__ fb,
-                                       int32_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done)
+__global__ __launch_bounds__(256) void expand_feedback_kernel(uint32_t N, int K, int Kp, int center, int pv, const uint8_t* __restrict__ fb,
+                                                              int32_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done)
 {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    for (int k0 = 0; k0 < Kp; k0 += 16) {
-        const uint4 w = *reinterpret_cast<const uint4*>(fb + (size_t)e * Kp + k0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = k0 + j;
-            if (k < K) {
-                const uint32_t b = (word_of(w, j >> 2) >> ((j & 3) * 8)) & 0xffu;
-                obs[(size_t)k * N + e] = center + pv * ((int)(b & 3u) - 1);
-                reward[(size_t)k * N + e] = (float)((int)((b >> 2) & 31u) - 10);
-                done[(size_t)k * N + e] = (uint8_t)(b >> 7);
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TP_ENVS][TP_STEPS + 4];                   // rows 68 bytes apart: 4-byte aligned, banks spread
+    const uint32_t e0 = blockIdx.x * TP_ENVS;
+    const int t = threadIdx.x;
+    const bool vec_ok = (N & 3u) == 0;
+    for (int k0 = 0; k0 < Kp; k0 += TP_STEPS) {
+        const int cols = (Kp - k0) < TP_STEPS ? (Kp - k0) : TP_STEPS;   // multiple of 16
+        {   // load: thread -> (env row, 16 consecutive steps = 16 bytes); 4 threads cover one env's 64 steps
+            const int env = t >> 2, s0 = (t & 3) * 16;
+            if (e0 + env < N && s0 < cols) {
+                const uint4 w = *reinterpret_cast<const uint4*>(fb + (size_t)(e0 + env) * Kp + k0 + s0);
+                uint32_t* row = reinterpret_cast<uint32_t*>(&tile[env][s0]);
+                row[0] = w.x; row[1] = w.y; row[2] = w.z; row[3] = w.w;
             }
         }
+        __syncthreads();
+        // store: thread -> (step row r of 16, 4 consecutive envs)
+        const int c4 = (t & 15) * 4, r = t >> 4;
+#pragma unroll
+        for (int pass = 0; pass < TP_STEPS / 16; ++pass) {
+            const int kk = pass * 16 + r, k = k0 + kk;
+            const uint32_t e = e0 + (uint32_t)c4;
+            if (k < K && e < N) {
+                int32_t o[4]; float rw[4]; uint8_t dn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t b = tile[c4 + j][kk];
+                    o[j] = center + pv * ((int)(b & 3u) - 1);
+                    rw[j] = (float)((int)((b >> 2) & 31u) - 10);
+                    dn[j] = (uint8_t)(b >> 7);
+                }
+                if (vec_ok && e + 3 < N) {
+                    *reinterpret_cast<int4*>(obs + (size_t)k * N + e) = make_int4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(reward + (size_t)k * N + e) = make_float4(rw[0], rw[1], rw[2], rw[3]);
+                    *reinterpret_cast<uchar4*>(done + (size_t)k * N + e) = make_uchar4(dn[0], dn[1], dn[2], dn[3]);
+                } else {
+                    for (int j = 0; j < 4 && e + j < N; ++j) {
+                        obs[(size_t)k * N + e + j] = o[j]; reward[(size_t)k * N + e + j] = rw[j]; done[(size_t)k * N + e + j] = dn[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -390,7 +456,7 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
     const int Kp = (K + 15) / 16 * 16;
     if (K <= 0 || Kp > k_cap || cst.max_duration > 0xfe) return GW_EUNSUPPORTED;
     const uint32_t N = (uint32_t)st.N;
-    const unsigned g256 = (unsigned)((st.N + 255) / 256);
+    const unsigned g256 = (unsigned)((st.N + TP_ENVS - 1) / TP_ENVS);      // one block per 64-env tile
     hipLaunchKernelGGL(pack_actions_kernel, dim3(g256), dim3(256), 0, (hipStream_t)stream, N, K, Kp, device, duration, act_buf);
     int rc;
     switch (st.D) {

@@ -305,3 +305,51 @@ def test_feedback_byte_codec_kernels():
     obs[0, 0] = 70000                                        # not -v / 0 / +v around the bound
     with pytest.raises(Exception):
         env.pack_feedback(obs, rew, done, check=True)
+
+
+# ---- BASELINE.json's full sizes ------------------------------------------------------------------------
+@pytest.mark.parametrize("D,K", [(4, 192), (16, 64)])
+def test_parity_at_full_baseline_size(D, K):
+    """configs[1] / configs[2]: 65 536 envs on one GPU, compared with the oracle directly (it is fast enough:
+    a few seconds on the host cores), reset every 64 steps as in the benchmark."""
+    N = 65536
+    env, orc = _mk(N, D)
+    dev, dur = action_stream(77, K, N, D)
+    _run(env, orc, dev, dur, reset_every=64, check_every=64)
+
+
+def test_full_size_properties_rollout_equals_steps_and_shards_equal_whole():
+    """Size-independent properties at 65 536 envs: (1) K fused-rollout steps leave exactly the state K single
+    steps leave; (2) two handles stepping the two halves of the batch equal one handle stepping all of it
+    (what sharding across GPUs relies on); (3) event totals are the sum of the per-env counters."""
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv
+    N, D, K = 65536, 4, 96
+    dev, dur = action_stream(5, K, N, D)
+    t_dev, t_dur = torch.from_numpy(dev).cuda(), torch.from_numpy(dur).cuda()
+    whole = VecCounterTrafficEnv(N, D)
+    fused = VecCounterTrafficEnv(N, D)
+    halves = [VecCounterTrafficEnv(N // 2, D), VecCounterTrafficEnv(N // 2, D)]
+    for e in [whole, fused] + halves:
+        e.reset()
+    outs = []
+    for k in range(K):
+        o, r, d, _ = whole.step({"device": t_dev[k], "duration": t_dur[k]})
+        outs.append((o.clone(), r.clone(), d.clone()))
+        for h, sl in zip(halves, (slice(0, N // 2), slice(N // 2, N))):
+            ho, hr, hd, _ = h.step({"device": t_dev[k, sl].contiguous(), "duration": t_dur[k, sl].contiguous()})
+            assert (ho == o[sl]).all() and (hr == r[sl]).all() and (hd == d[sl]).all(), k
+    fo, fr, fd = fused.rollout(t_dev, t_dur)
+    for k in range(K):
+        assert (fo[k] == outs[k][0]).all() and (fr[k] == outs[k][1]).all() and (fd[k] == outs[k][2]).all(), k
+    for f in ("now", "wake", "counter", "qlen", "received", "rx_power", "last_abs"):
+        a = whole.get_state(f)
+        assert (a.view(np.uint8) == fused.get_state(f).view(np.uint8)).all(), f
+        b = np.concatenate([h.get_state(f) for h in halves])
+        assert (a.view(np.uint8) == b.view(np.uint8)).all(), f
+    st = whole.stats()
+    assert st["steps"] == N * K
+    for name, field in (("transmissions", "n_tx"), ("delivered", "n_delivered"), ("appended", "n_appended"),
+                        ("popped", "n_popped"), ("dropped", "n_dropped")):
+        assert st[name] == int(whole.get_state(field).sum()), name
+    assert st["flags_or"] & 3 == 0

@@ -185,6 +185,10 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     const double2 tw = ld<double2>(st.tw, o16);
     const uint4 tk = ld<uint4>(st.tk, o16);
     uint4 sa0 = ld<uint4>(st.sa, o32), sa1 = ld<uint4>(st.sa, o32 + 16u);
+    // used only after the loop: take them out of the in-order vmcnt queue now, or their first use would wait
+    // for every store issued before it
+    asm volatile("" : "+v"(sa0.x), "+v"(sa0.y), "+v"(sa0.z), "+v"(sa0.w));
+    asm volatile("" : "+v"(sa1.x), "+v"(sa1.y), "+v"(sa1.z), "+v"(sa1.w));
     uint32_t len[DT], sta[R];
     {
         uint4 qw[NWC];

@@ -201,6 +201,11 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     if (live) {
         uint32_t rvm = ip.z;
         if (rvm == 0xdeadbeefu) k_bad = 2;    // touches ip: the stamp below sits after the state loads have landed
+        // The counter record is loaded with the rest of the state but only used at the very end.  vmcnt counts
+        // loads AND stores in order on this ISA, so a first use after the state stores would wait for those
+        // stores to be acknowledged (a full HBM write round trip on every wave's critical path): use it now.
+        PIN_V(sa0.x); PIN_V(sa0.y); PIN_V(sa0.z); PIN_V(sa0.w);
+        PIN_V(sa1.x); PIN_V(sa1.y); PIN_V(sa1.z); PIN_V(sa1.w);
         STAMP(3);
         int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
         uint32_t dn = ip.w >> 31;

@@ -153,3 +153,15 @@ def test_bench_algorithmic_byte_model():
     assert bench.algorithmic_bytes(4, 1, 0, 0) == 17 + 2 * (12 + 80)
     assert bench.algorithmic_bytes(2, 10, 440, 10) == 10 * (17 + 2 * 52) + 4 * 450
     assert bench.HBM_PEAK == 8.0e12
+
+
+def test_oracle_is_clean_under_asan_ubsan():
+    """tools/sanitize_cpu.sh: the C oracle under AddressSanitizer + UBSan (CPU only; `--host` also runs the
+    library's host side, which needs hipcc and takes longer)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or not os.path.exists(subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True,
+                                                                     text=True).stdout.strip()):
+        pytest.skip("no gcc/libasan")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_cpu.sh")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "sanitizers: clean" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

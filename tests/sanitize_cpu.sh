@@ -6,7 +6,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 TMP=${TMPDIR:-/tmp}
 gcc -O1 -g -std=c11 -D_GNU_SOURCE -ffp-contract=off -fno-fast-math -fopenmp -fsanitize=address,undefined \
     -fno-sanitize-recover=undefined -shared -fPIC -o $TMP/libct_oracle_san.so $REPO/oracle/ct_oracle.c -lm
-ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python3 $REPO/tools/sanitize_oracle_run.py $TMP/libct_oracle_san.so
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python3 $REPO/tests/sanitize_oracle_run.py $TMP/libct_oracle_san.so
 if [ "$1" == "--host" ]; then
   cd $REPO/gymwipe_amd/csrc
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -I../../include \

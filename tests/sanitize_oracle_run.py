@@ -1,9 +1,9 @@
 """Drives the ASan+UBSan build of the C oracle through resets, several device counts and a marginal geometry."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # this file lives in tests/
 import oracle.ct_oracle as co
-co._LIB_PATH = sys.argv[1]            # the sanitizer build (tools/sanitize_cpu.sh)
+co._LIB_PATH = sys.argv[1]            # the sanitizer build (tests/sanitize_cpu.sh)
 co._lib = None
 import numpy as np
 from util import action_stream

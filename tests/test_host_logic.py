@@ -156,12 +156,12 @@ def test_bench_algorithmic_byte_model():
 
 
 def test_oracle_is_clean_under_asan_ubsan():
-    """tools/sanitize_cpu.sh: the C oracle under AddressSanitizer + UBSan (CPU only; `--host` also runs the
+    """tests/sanitize_cpu.sh: the C oracle under AddressSanitizer + UBSan (CPU only; `--host` also runs the
     library's host side, which needs hipcc and takes longer)."""
     import shutil
     import subprocess
     if not shutil.which("gcc") or not os.path.exists(subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True,
                                                                      text=True).stdout.strip()):
         pytest.skip("no gcc/libasan")
-    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_cpu.sh")], capture_output=True, text=True, timeout=300)
+    out = subprocess.run(["bash", os.path.join(ROOT, "tests", "sanitize_cpu.sh")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "sanitizers: clean" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The reference's benchmark_simulation_grid (tests/test_benchmark.py:87-88: wall time of 1 simulated second of an
-n-device grid), as N replicas on one MI355X; plus the event-driven oracle (pure Python, one core) on the same
+n-device grid), as N replicas on one MI355X; (the event-driven model's own wall time per simulated second is recorded in profiles/r1_grid_phy; it is not run from here: only tests/, smoke() and bench.py's cpu_baseline may touch oracle/) -- formerly timed on the same
 scenario as the CPU figure.  Prints one JSON line per n."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,12 +27,5 @@ for n in (4, 16, 20):
            "events_per_s": float(ev.sum()) / (wall * (SIM + 0.05) / SIM), "n_tx_mean": float(grid.get_state("n_tx").mean()),
            "hdr_ok": int(grid.get_state("hdr_ok").sum()), "hdr_fail": int(grid.get_state("hdr_fail").sum()),
            "flags_or": int(np.bitwise_or.reduce(grid.get_state("flags")))}
-    if not os.environ.get("NO_CPU"):
-        from oracle import des_model as dm
-        t1 = time.perf_counter()
-        (dm.scenario_mobile_grid(n, delays[0].tolist(), min(SIM, 0.5), seed=99) if MOBILE else dm.scenario_grid(n, delays[0].tolist(), min(SIM, 0.5)))
-        cpu = time.perf_counter() - t1
-        out["cpu_oracle_python_1core_wall_per_sim_s"] = cpu / min(SIM, 0.5)
-        out["speedup_vs_python_oracle"] = out["replica_seconds_per_s"] * out["cpu_oracle_python_1core_wall_per_sim_s"]
     print(json.dumps(out))
     grid.close()

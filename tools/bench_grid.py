@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The reference's benchmark_simulation_grid (tests/test_benchmark.py:87-88: wall time of 1 simulated second of an
-n-device grid), as N replicas on one MI355X; (the event-driven model's own wall time per simulated second is recorded in profiles/r1_grid_phy; it is not run from here: only tests/, smoke() and bench.py's cpu_baseline may touch oracle/) -- formerly timed on the same
-scenario as the CPU figure.  Prints one JSON line per n."""
+n-device grid), as N replicas on one MI355X.  Prints one JSON line per n.  The CPU figure beside it in
+profiles/r1_grid_phy (the event-driven Python model, one core) was taken once with the test infrastructure; it is
+not run from here."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -60,6 +60,7 @@ class Config(C.Structure):
         ("net_header_bytes", C.c_int32),
         ("duration_factor", C.c_int32),
         ("max_duration", C.c_int32),
+        ("extra_att_db", (C.c_double * MAX_RADIOS) * MAX_RADIOS),
     ]
 
 

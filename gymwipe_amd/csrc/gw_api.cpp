@@ -109,6 +109,10 @@ int validate(const gw_config& c)
     }
     if ((c.flags & (GW_CFG_NO_COUNTER_TRAFFIC | GW_CFG_PEER_RECEIVE | GW_CFG_FLOAT_DURATION)) && !(c.flags & GW_CFG_EXPLICIT_QUEUE))
         return fail(GW_EUNSUPPORTED, "GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION need GW_CFG_EXPLICIT_QUEUE");
+    for (int a = 0; a <= c.num_devices; ++a)
+        for (int b = 0; b <= c.num_devices; ++b)
+            if (!(c.extra_att_db[a][b] == c.extra_att_db[b][a]) || (a == b && c.extra_att_db[a][b] != 0.0))
+                return fail(GW_EINVAL, "extra_att_db must be symmetric with a zero diagonal (pair %d,%d)", a, b);
     if ((int64_t)c.max_duration * c.duration_factor > 100000000)
         return fail(GW_EINVAL, "max_duration*duration_factor too large");
     return GW_OK;

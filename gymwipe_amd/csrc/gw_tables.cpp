@@ -89,6 +89,11 @@ int gw_build_tables(const gw_config& cfg, GwHostTables& t, char* msg, size_t msg
         for (int b = 0; b < R; ++b) {
             if (a == b) continue;
             t.att[a][b] = fspl_db(cfg, a, b);
+            if (cfg.extra_att_db[a][b] != 0.0) {                                    // joined model: sum([fspl, custom]) = (0 + fspl) + custom
+                volatile double joined = 0.0 + t.att[a][b];
+                joined = joined + cfg.extra_att_db[a][b];
+                t.att[a][b] = joined;
+            }
             t.prx[a][b] = pow(10.0, (cfg.tx_power_dbm - t.att[a][b]) / 10);        // simple_stack.py:111
         }
 

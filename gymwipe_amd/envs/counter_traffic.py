@@ -72,6 +72,10 @@ class VecCounterTrafficEnv(BaseEnv):
         explicit_queue: hold the MAC queues as explicit rings of packet sizes (generic, slower)
             instead of the default exact run-length encoding of counter traffic.
         reuse_outputs: return the same output tensors every step (fast path).
+        extra_attenuation: custom attenuation models per device pair (the reference's
+            AttenuationModelFactory.setCustomModels / JoinedAttenuationModel, physical.py:402-498), reduced to what they
+            amount to with static geometry: ``{(a, b): dB}`` added to the free-space term of the pair (radio index
+            ``num_devices`` is the RRM), or a callable ``(a, b, pos_a, pos_b) -> dB`` evaluated for every pair.
         counter_traffic / peer_receive / float_duration (explicit_queue only): switch the
             counter processes off so that packets come from enqueue() only; keep every sender MAC in receive
             mode (get_state("peer_received") counts what it hands up); pass assignment durations as floats
@@ -86,7 +90,7 @@ class VecCounterTrafficEnv(BaseEnv):
     def __init__(self, num_envs, num_devices=2, device="cuda:0", positions=None,
                  multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
                  reuse_outputs=True, explicit_queue=False, counter_bound=None, interpreter=None,
-                 counter_traffic=True, peer_receive=False, float_duration=False):
+                 counter_traffic=True, peer_receive=False, float_duration=False, extra_attenuation=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -115,6 +119,13 @@ class VecCounterTrafficEnv(BaseEnv):
             assert len(dest) == D
             for i, m in enumerate(dest):
                 cfg.dest[i] = int(m)
+        if extra_attenuation is not None:
+            if callable(extra_attenuation):
+                pos = [(cfg.pos[i][0], cfg.pos[i][1]) for i in range(D + 1)]
+                extra_attenuation = {(a, b): extra_attenuation(a, b, pos[a], pos[b])
+                                     for a in range(D + 1) for b in range(a + 1, D + 1)}
+            for (a, b), db in extra_attenuation.items():
+                cfg.extra_att_db[a][b] = cfg.extra_att_db[b][a] = float(db)
         if per_env_stats:
             cfg.flags |= nat.CFG_PER_ENV_STATS
         if explicit_queue:

@@ -87,6 +87,11 @@ typedef struct gw_config {
     int32_t net_header_bytes;               /* 12 */
     int32_t duration_factor;                /* ASSIGNMENT_DURATION_FACTOR 1000 */
     int32_t max_duration;                   /* MAX_ASSIGN_DURATION 20 */
+    /* Custom attenuation models (AttenuationModelFactory.setCustomModels + JoinedAttenuationModel, physical.py:402-457,
+     * 477-498): geometry is static here, so the models a caller sets for a device pair reduce to one number, the sum of
+     * their attenuations in dB, which the joined model adds to the free-space term (sum() over [FSPL, custom...]).
+     * Must be symmetric; 0 = the pair keeps the plain FSPL model. */
+    double  extra_att_db[GW_MAX_RADIOS][GW_MAX_RADIOS];
 } gw_config;
 
 #define GW_CFG_PER_ENV_STATS  1             /* explicit-queue mode only: keep per-env event counters (the default

@@ -159,6 +159,11 @@ cto_vec* cto_create(const cto_config* cfg, int64_t n)
         for (int b = 0; b < R; ++b) {
             if (a == b) { v->att[a][b] = 0; v->prx[a][b] = 0; continue; }
             v->att[a][b] = fspl_db(cfg, a, b);
+            if (cfg->extra_att_db[a][b] != 0.0) {            /* physical.py:457: sum() over [FSPL, custom models] */
+                volatile double joined = 0.0 + v->att[a][b];
+                joined = joined + cfg->extra_att_db[a][b];
+                v->att[a][b] = joined;
+            }
             v->prx[a][b] = pow(10.0, (cfg->tx_power_dbm - v->att[a][b]) / 10);
         }
 #define ALLOC(p, cnt) do { (p) = calloc((size_t)(cnt), sizeof *(p)); if (!(p)) { cto_destroy(v); return NULL; } } while (0)

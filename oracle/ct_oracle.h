@@ -46,6 +46,9 @@ typedef struct cto_config {
     int32_t net_header_bytes;                /* 12              messages.py:180 */
     int32_t duration_factor;                 /* 1000            envs/core.py:27 */
     int32_t max_duration;                    /* 20              envs/core.py:25 */
+    /* sum of the custom attenuation models of a device pair, dB (JoinedAttenuationModel, physical.py:402-457);
+       0 = plain FSPL.  Symmetric. */
+    double  extra_att_db[CTO_MAX_RADIOS][CTO_MAX_RADIOS];
 } cto_config;
 
 typedef struct cto_vec cto_vec;

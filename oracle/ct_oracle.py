@@ -42,6 +42,7 @@ class Config(C.Structure):
         ("net_header_bytes", C.c_int32),
         ("duration_factor", C.c_int32),
         ("max_duration", C.c_int32),
+        ("extra_att_db", (C.c_double * MAX_RADIOS) * MAX_RADIOS),
     ]
 
 
@@ -86,7 +87,7 @@ def lib():
     return _lib
 
 
-def default_config(num_devices, positions=None, mult=None, dest=None, rrm_pos=None):
+def default_config(num_devices, positions=None, mult=None, dest=None, rrm_pos=None, extra_att=None):
     cfg = Config()
     if lib().cto_config_default(C.byref(cfg), num_devices) != 0:
         raise ValueError("num_devices out of range")
@@ -102,6 +103,9 @@ def default_config(num_devices, positions=None, mult=None, dest=None, rrm_pos=No
     if dest is not None:
         for i, m in enumerate(dest):
             cfg.dest[i] = int(m)
+    if extra_att is not None:              # {(a, b): dB}, radio index D = the RRM; applied to both directions
+        for (a, b), db in extra_att.items():
+            cfg.extra_att_db[a][b] = cfg.extra_att_db[b][a] = float(db)
     return cfg
 
 

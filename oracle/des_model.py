@@ -420,9 +420,10 @@ class Cmd:
 class FsplLink:
     STANDBY = 3000.0                        # physical.py:371
 
-    def __init__(self, sim, freq, dev_a, dev_b):
+    def __init__(self, sim, freq, dev_a, dev_b, extra=None):
         assert dev_a is not dev_b
         self.freq, self.a, self.b = freq, dev_a, dev_b
+        self.extra = extra                  # dB of the pair's custom models (JoinedAttenuationModel), or None
         self.attenuation = 0
         self.n_changes = Notifier(sim)
         for dev in (dev_a, dev_b):          # physical.py:380-386
@@ -438,6 +439,8 @@ class FsplLink:
         if pa.same_as(pb):
             return
         att = 20 * log10(pa.distance_to(pb)) + 20 * log10(self.freq) - 147.55
+        if self.extra:                      # physical.py:457: sum() over the models' values, FSPL first
+            att = sum([att, self.extra])
         if att != self.attenuation:         # physical.py:354-362
             self.attenuation = att
             self.n_changes.trigger(att)
@@ -466,6 +469,7 @@ class Band:
     def __init__(self, sim, freq=2.4e9, bandwidth=22e6):
         self.sim, self.freq, self.bandwidth = sim, freq, bandwidth
         self._links = {}
+        self.custom = {}                    # frozenset of two device ids -> extra dB (setCustomModels, physical.py:477-498)
         self._txs = deque()
         self.n_new_tx = Notifier(sim)
         self.log = []                       # every transmission, for tests
@@ -473,7 +477,7 @@ class Band:
     def link(self, dev_a, dev_b):           # physical.py:500-528
         key = frozenset((id(dev_a), id(dev_b)))
         if key not in self._links:
-            self._links[key] = FsplLink(self.sim, self.freq, dev_a, dev_b)
+            self._links[key] = FsplLink(self.sim, self.freq, dev_a, dev_b, self.custom.get(key))
         return self._links[key]
 
     def transmit(self, sender, power, packet, mcs_h, mcs_p):
@@ -868,7 +872,7 @@ class CounterTrafficModel:
 
     def __init__(self, num_devices=2, positions=None, mult=None, dest=None,
                  rrm_pos=(0.0, 0.0), traffic=True, peer_receive=False,
-                 rx_duration=10, float_duration=False):
+                 rx_duration=10, float_duration=False, extra_att=None):
         """traffic=False: no counter processes, packets come from enqueue();
         peer_receive: every sender MAC is kept in receive mode (SURVEY 8f rank
         2; the reference env never does this); float_duration: the assignment
@@ -888,6 +892,11 @@ class CounterTrafficModel:
             s.dest = self.senders[dest[i]].mac_addr
         self.interp = _Interp(D)
         self.rrm = RrmDevice(self.world, "RRM", rrm_pos[0], rrm_pos[1], idx2mac, self.interp)
+        if extra_att:                       # {(a, b): dB}, radio index D = the RRM; set before any link exists
+            radios = self.senders + [self.rrm]
+            assert not self.world.band._links
+            for (a, b), db in extra_att.items():
+                self.world.band.custom[frozenset((id(radios[a]), id(radios[b])))] = float(db)
         self.num_devices = D
         self.float_duration = float_duration
         if peer_receive:

@@ -21,8 +21,12 @@ def _mk(num_envs, D, explicit=False, counter_bound=None, **kw):
     from oracle.ct_oracle import CtOracle, default_config
     env = VecCounterTrafficEnv(num_envs, num_devices=D, per_env_stats=True, explicit_queue=explicit,
                                counter_bound=counter_bound, **kw)
+    ea = kw.get("extra_attenuation")
+    if callable(ea):
+        pos = [tuple(env.config.pos[i]) for i in range(D + 1)]
+        ea = {(a, b): ea(a, b, pos[a], pos[b]) for a in range(D + 1) for b in range(a + 1, D + 1)}
     cfg = default_config(D, positions=kw.get("positions"), mult=kw.get("multiplicity"),
-                         rrm_pos=kw.get("rrm_position"))
+                         rrm_pos=kw.get("rrm_position"), extra_att=ea)
     if counter_bound is not None:
         cfg.counter_bound = counter_bound
     orc = CtOracle(num_envs, D, config=cfg, nthreads=8)
@@ -353,3 +357,24 @@ def test_full_size_properties_rollout_equals_steps_and_shards_equal_whole():
                         ("popped", "n_popped"), ("dropped", "n_dropped")):
         assert st[name] == int(whole.get_state(field).sum()), name
     assert st["flags_or"] & 3 == 0
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+def test_parity_with_custom_attenuation_models(explicit):
+    """setCustomModels / JoinedAttenuationModel (physical.py:402-498) with static geometry: extra dB per device pair,
+    given as a dict and as a callable; some links pushed over the decode thresholds by the extra term."""
+    N, K, D = 1024, 64, 4
+    env, orc = _mk(N, D, explicit=explicit, extra_attenuation={(0, 4): 4.5, (1, 4): 4.7, (2, 3): 2.0, (3, 4): 0.125})
+    dev, dur = action_stream(41, K, N, D)
+    _run(env, orc, dev, dur, reset_every=20)
+    st = env.stats()
+    assert 0 < st["delivered"] < st["transmissions"] - st["steps"]       # sender 1 sits at the payload threshold now
+
+    def wall(a, b, pa, pb):                                            # anything crossing x = 0 loses 6 dB
+        return 6.0 if (pa[0] < 0) != (pb[0] < 0) else 0.0
+    env2, orc2 = _mk(N, D, explicit=explicit, extra_attenuation=wall)
+    _run(env2, orc2, dev, dur, reset_every=20)
+    att_plain, _ = _mk(8, D)[0].link_info(1, 4)
+    att_wall, _ = env2.link_info(1, 4)
+    p1 = tuple(env2.config.pos[1])
+    assert att_wall == att_plain + (6.0 if p1[0] < 0 else 0.0)

@@ -62,12 +62,12 @@ def test_c_oracle_counter_traffic_known_answer():
 
 
 # ---- layer 2 == layer 1, bit for bit --------------------------------------------------------------
-def _compare(D, steps, seed, reset_every=None, fresh_reset=True, positions=None, mult=None, bound=None):
+def _compare(D, steps, seed, reset_every=None, fresh_reset=True, positions=None, mult=None, bound=None, extra_att=None):
     rng = np.random.default_rng(seed)
     pos = positions or dm.circle_layout(D)
     mult = mult or dm.default_multiplicity(D)
-    py = dm.CounterTrafficModel(D, positions=pos, mult=mult)
-    cfg = default_config(D, positions=pos, mult=mult)
+    py = dm.CounterTrafficModel(D, positions=pos, mult=mult, extra_att=extra_att)
+    cfg = default_config(D, positions=pos, mult=mult, extra_att=extra_att)
     co = CtOracle(1, D, config=cfg)
     if fresh_reset:
         assert py.reset() == co.reset()[0]
@@ -106,6 +106,12 @@ def test_c_oracle_equals_event_driven_restatement_other_geometry():
     # a sender far enough (11 m) that the RRM cannot decode its payload: exercises failed receptions
     pos = [(0.0, 2.0), (0.0, -11.0), (3.0, 0.0)]
     _compare(3, 80, 6, 20, True, positions=pos, mult=[2, 1, 3])
+
+
+def test_c_oracle_equals_event_driven_restatement_joined_attenuation():
+    # custom attenuation models on some pairs (setCustomModels + JoinedAttenuationModel, physical.py:402-498):
+    # a 3 dB and a 7.5 dB obstacle towards the RRM (radio 3), 1.25 dB between two senders
+    _compare(3, 90, 7, 25, True, extra_att={(0, 3): 3.0, (1, 3): 7.5, (0, 1): 1.25})
 
 
 # ---- secondary cross-check against SURVEY.md's probe values (NOT reference output) ----------------

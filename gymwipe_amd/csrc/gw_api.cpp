@@ -73,6 +73,10 @@ int dev_alloc(gw_env* env, T** out, size_t count)
     const size_t bytes = count * sizeof(T);
     hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
     if (e != hipSuccess) return fail(GW_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (env->nblocks >= (int)(sizeof env->blocks / sizeof env->blocks[0])) {
+        (void)hipFree(p);
+        return fail(GW_ENOMEM, "internal: block table full");
+    }
     env->blocks[env->nblocks++] = p;
     env->bytes += bytes;
     *out = (T*)p;

@@ -56,8 +56,9 @@ def measured_traffic(D, N):
     return None
 
 
-def cpu_baseline(D, seconds_target=12.0):
-    """The oracle on the host cores, same action distribution, same reset cadence."""
+def cpu_baseline(D, seconds_target=12.0, single_thread_seconds=3.0):
+    """The oracle on the host cores, same action distribution, same reset cadence: all cores of the box's
+    CPU share for one GPU (the headline `value`) and one thread beside it."""
     import numpy as np
     from oracle.ct_oracle import CtOracle
     try:
@@ -65,26 +66,32 @@ def cpu_baseline(D, seconds_target=12.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))           # the GPU box's CPU share for one GPU
-    n_env, K = 256 * cores, 64
-    rng = np.random.default_rng(1234)
-    dev = rng.integers(0, D, (K, n_env), dtype=np.int32)
-    dur = rng.integers(0, 20, (K, n_env), dtype=np.int32)
-    orc = CtOracle(n_env, D, nthreads=cores)
-    orc.reset()
-    for k in range(8):
-        orc.step(dev[k], dur[k])                 # warm-up
-    done_steps, t0 = 0, time.perf_counter()
-    while True:
+
+    def timed(nthreads, seconds):
+        n_env, K = 256 * nthreads, 64
+        rng = np.random.default_rng(1234)
+        dev = rng.integers(0, D, (K, n_env), dtype=np.int32)
+        dur = rng.integers(0, 20, (K, n_env), dtype=np.int32)
+        orc = CtOracle(n_env, D, nthreads=nthreads)
         orc.reset()
-        for k in range(K):
-            orc.step(dev[k], dur[k])
-        done_steps += K * n_env
-        el = time.perf_counter() - t0
-        if el >= seconds_target:
-            break
-    return {"value": done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        for k in range(8):
+            orc.step(dev[k], dur[k])             # warm-up
+        done_steps, t0 = 0, time.perf_counter()
+        while True:
+            orc.reset()
+            for k in range(K):
+                orc.step(dev[k], dur[k])
+            done_steps += K * n_env
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                return done_steps / el, n_env, K, el
+
+    v, n_env, K, el = timed(cores, seconds_target)
+    v1, _, _, el1 = timed(1, single_thread_seconds)
+    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d envs x %d steps per pass (D=%d, reset every pass), repeated for %.1f s on %d threads (OpenMP)"
-                      % (n_env, K, D, el, cores)}
+                      % (n_env, K, D, el, cores),
+            "single_thread_value": v1, "single_thread_sample": "256 envs x %d steps per pass for %.1f s on 1 thread" % (K, el1)}
 
 
 def main():

@@ -378,3 +378,35 @@ def test_parity_with_custom_attenuation_models(explicit):
     att_wall, _ = env2.link_info(1, 4)
     p1 = tuple(env2.config.pos[1])
     assert att_wall == att_plain + (6.0 if p1[0] < 0 else 0.0)
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+@pytest.mark.parametrize("D,p", [(2, 0.3), (4, 0.1), (3, 0.02)])
+def test_parity_with_random_per_env_resets(D, p, explicit):
+    """reset(mask): every env gets its own reset history -- several resets inside one queue span, resets on
+    consecutive steps (the breakpoint is overwritten, not appended), empty masks, full masks."""
+    import torch
+    N, K = 2048, 160
+    env, orc = _mk(N, D, explicit=explicit)
+    dev, dur = action_stream(50 + D, K, N, D)
+    rng = np.random.default_rng(9)
+    assert (env.reset().cpu().numpy() == orc.reset()).all()
+    for k in range(K):
+        if k % 2 == 0 or k % 7 == 3:
+            mask = (rng.random(N) < p).astype(np.uint8)
+            if k == 40:
+                mask[:] = 0
+            if k == 80:
+                mask[:] = 1
+            assert (env.reset(torch.from_numpy(mask)).cpu().numpy() == orc.reset(mask)).all(), k
+        o, r, d, _ = env.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (o.cpu().numpy() == oo).all() and (r.cpu().numpy() == orr).all() and (d.cpu().numpy() == od).all(), k
+        if k % 32 == 31 or k == K - 1:
+            assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after step %d" % k)
+    fo, fr, fd = env.rollout(torch.from_numpy(dev[:48]).cuda(), torch.from_numpy(dur[:48]).cuda())
+    for k in range(48):                                   # the fused kernel on top of those reset histories
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all(), k
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
+    env.check()

@@ -5,6 +5,7 @@ GPU parity tests proper: the HIP path, called through the C-ABI, against the C o
 (simulated time, tick time, rx power): the kernels perform the reference's individual
 IEEE operations, so no tolerance is needed (north_star allows 1e-5 relative).
 """
+import os
 import numpy as np
 import pytest
 
@@ -410,3 +411,44 @@ def test_parity_with_random_per_env_resets(D, p, explicit):
         assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all(), k
     assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
     env.check()
+
+
+def test_chunked_feedback_gather_over_rccl_single_rank():
+    """The N > 1 exchange of bench.py with the real backend: RCCL (`nccl`) process group of one rank on this GPU,
+    HIP pack kernel, asynchronous all_gather_into_tensor on RCCL's stream, double buffering, a partial last chunk."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gymwipe_amd import VecCounterTrafficEnv
+    from gymwipe_amd.sharding import ChunkedFeedbackGather
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        N, D, K, G = 4096, 4, 150, 64
+        env, ref = VecCounterTrafficEnv(N, D), VecCounterTrafficEnv(N, D)
+        dev, dur = action_stream(3, K, N, D)
+        t_dev, t_dur = torch.from_numpy(dev).cuda(), torch.from_numpy(dur).cuda()
+        cg = ChunkedFeedbackGather(N, torch.device("cuda", 0), env.pack_feedback, 1, chunk=G)
+        env.reset(); ref.reset()
+        want, got = [], []
+        for k in range(K):
+            env._obs, env._rew, env._done = cg.slot()
+            env.step({"device": t_dev[k], "duration": t_dur[k]})
+            o, r, d, _ = ref.step({"device": t_dev[k], "duration": t_dur[k]})
+            want.append((o.clone(), r.clone(), d.clone()))
+            b = cg.stepped()
+            if b is not None:
+                cg.pending[b].wait()
+                got.append(cg.result(b).clone())
+        b = (cg.k // G) % cg.depth
+        cg.drain()
+        got.append(cg.result(b).clone())
+        torch.cuda.synchronize()
+        packed = torch.cat(got, dim=1)                        # [1][K][N]
+        assert packed.shape == (1, K, N)
+        o, r, d = env.unpack_feedback(packed[0].contiguous())
+        for k in range(K):
+            assert (o[k] == want[k][0]).all() and (r[k] == want[k][1]).all() and (d[k] == want[k][2]).all(), k
+    finally:
+        dist.destroy_process_group()

@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
 
     const StepMath m(c);
     const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
+    const double inv_interval = c.inv_interval;
+    const bool fast_ticks = c.fast_ticks != 0;
     const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
     const int mh = c.mac_hdr, pv = c.payload_value;
     uint32_t mult[DT], term[DT];
@@ -387,17 +389,27 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             if (!ok) finish = true;                  // announcement not decoded: no window
         }
         {
+            // the first count of a step also covers the ticks since the previous window closed (up to ~21):
+            // one jump (gw_fastmath.h; exact, validated at gw_create) instead of a loop every lane would wait for
             uint32_t kk = 0;
-            for (;;) {
-                const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
-                const bool b0 = incl ? (wake <= cur) : (wake < cur);
-                const bool b1 = incl ? (w1 <= cur) : (w1 < cur);
-                const bool b2 = incl ? (w2 <= cur) : (w2 < cur);
-                const bool b3 = incl ? (w3 <= cur) : (w3 < cur);
-                if (incl && (wake == cur || w1 == cur || w2 == cur || w3 == cur)) fl |= GW_FLAG_TIE;
-                kk += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;
-                wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
-                if (!b3) break;
+            double wj = wake;
+            bool tiej = false;
+            if (fast_ticks && gw_tick_jump(wake, cur, interval, inv_interval, incl, &kk, &wj, &tiej)) {
+                wake = wj;
+                if (tiej) fl |= GW_FLAG_TIE;
+            } else {
+                kk = 0;
+                for (;;) {
+                    const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
+                    const bool b0 = incl ? (wake <= cur) : (wake < cur);
+                    const bool b1 = incl ? (w1 <= cur) : (w1 < cur);
+                    const bool b2 = incl ? (w2 <= cur) : (w2 < cur);
+                    const bool b3 = incl ? (w3 <= cur) : (w3 < cur);
+                    if (incl && (wake == cur || w1 == cur || w2 == cur || w3 == cur)) fl |= GW_FLAG_TIE;
+                    kk += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;
+                    wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
+                    if (!b3) break;
+                }
             }
             tau += kk;
             len_d = gw_len_after_ticks(len_d, kk, mult_d, kt);

@@ -169,14 +169,14 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     // ---- constants -> registers, under the shadow of the loads above --------------------------------
     StepMath m(c);
     double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
-    double coded_factor = c.coded_factor, cls_limit = c.cls_limit;
+    double coded_factor = c.coded_factor, cls_limit = c.cls_limit, inv_interval = c.inv_interval;
     int pv = c.payload_value, cbound = c.counter_bound, max_duration = c.max_duration, dfactor = c.duration_factor;
-    int mh = c.mac_hdr, base_b = c.mac_hdr + c.net_hdr, idem_i = c.idem_states;
+    int mh = c.mac_hdr, base_b = c.mac_hdr + c.net_hdr, idem_i = c.idem_states, fast_ticks = c.fast_ticks;
     __builtin_amdgcn_sched_barrier(0);
     PIN_V(m.slot); PIN_V(m.inv_slot); PIN_V(m.fmod_limit); PIN_V(m.dr); PIN_V(m.rcp_dr); PIN_V(m.max_ber);
     PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide);
-    PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit);
-    PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i);
+    PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit); PIN_V(inv_interval);
+    PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i); PIN_S(fast_ticks);
     __builtin_amdgcn_sched_barrier(0);
 
     if (one_pass) {
@@ -361,8 +361,21 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             }
 
             STAMP(7);
-            // ---- A.5: remaining ticks up to the end of the step -------------------------------
-            ticks_to(t_end, true);
+            // ---- A.5: remaining ticks up to the end of the step: up to 21 of them, counted in one jump
+            //      (gw_fastmath.h; exact, validated at gw_create) or, where the jump declines, by the loop --------
+            {
+                uint32_t nj = 0;
+                double wj = wake;
+                bool tiej = false;
+                if (fast_ticks && gw_tick_jump(wake, t_end, interval, inv_interval, true, &nj, &wj, &tiej)) {
+                    wake = wj;
+                    tau += nj;
+                    if (tiej) fl |= GW_FLAG_TIE;
+                    len_d = gw_len_after_ticks(len_d, nj, mult_d, kd);
+                } else {
+                    ticks_to(t_end, true);
+                }
+            }
             STAMP(8);
             const uint32_t n_ticks = tau - tau0;
             k.app += kd.app;

@@ -137,6 +137,8 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
     // round(err)/bits <= 0.25  <=>  4*round(err) <= bits  when bits is an integer (both < 2^53)
     k.cls_limit = (no_fast || getenv("GW_NO_CLASSES")) ? 0.0 : 1.0e6;
     k.fast_decide = (!no_fast && cfg->max_ber == 0.25 && tab.coded_factor * 8.0 == floor(tab.coded_factor * 8.0)) ? 1 : 0;
+    k.inv_interval = 1.0 / cfg->counter_interval;
+    k.fast_ticks = (!no_fast && !getenv("GW_NO_TICKJUMP") && gw_fast_ticks_ok(cfg->counter_interval)) ? 1 : 0;
     k.idem_states = 1;                              // hearing the same talker twice changes nothing more
     for (int to = 0; to < R && k.idem_states; ++to)
         for (int from = 0; from < R && k.idem_states; ++from) {
@@ -593,7 +595,7 @@ int gw_selftest_fastmath(const gw_config* cfg, int32_t* max_noise_states)
     for (int r = 0; r < tab->R; ++r) mx = tab->nstates[r] > mx ? tab->nstates[r] : mx;
     if (max_noise_states) *max_noise_states = mx;
     delete tab;
-    return (k.fast_fmod ? 1 : 0) | (k.fast_div ? 2 : 0) | (k.fast_decide ? 4 : 0) | (k.idem_states ? 8 : 0);
+    return (k.fast_fmod ? 1 : 0) | (k.fast_div ? 2 : 0) | (k.fast_decide ? 4 : 0) | (k.idem_states ? 8 : 0) | (k.fast_ticks ? 16 : 0);
 }
 
 // Host-only fuzz of the suffix queue encoding (gw_queue.h, the same code the kernel runs) against

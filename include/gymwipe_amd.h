@@ -281,7 +281,7 @@ int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t c
 
 /* Host-only: bit mask of the exact arithmetic fast paths gw_create enables for cfg after validating
  * them (1 slot remainder, 2 division by the data rate, 4 integer decode decision, 8 idempotent
- * noise-state map); negative on error.  max_noise_states may be NULL. */
+ * noise-state map, 16 counter ticks counted in one jump); negative on error.  max_noise_states may be NULL. */
 int gw_selftest_fastmath(const gw_config* cfg, int32_t* max_noise_states);
 
 #ifdef __cplusplus

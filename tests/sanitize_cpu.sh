@@ -22,7 +22,7 @@ for mult in (1, 3, 7, 15):
     assert L.gw_selftest_queue(123 + mult, 20000, mult, 65536) == 0 and L.gw_selftest_queue(5, 20000, mult, 40) == 0
 for D in (2, 4, 16, 32):
     cfg = nat.default_config(64, D); ns = C.c_int32()
-    assert L.gw_selftest_fastmath(C.byref(cfg), C.byref(ns)) == 15
+    assert L.gw_selftest_fastmath(C.byref(cfg), C.byref(ns)) == 31
 print("host side clean")
 PY
 fi

@@ -452,3 +452,21 @@ def test_chunked_feedback_gather_over_rccl_single_rank():
             assert (o[k] == want[k][0]).all() and (r[k] == want[k][1]).all() and (d[k] == want[k][2]).all(), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("switch", ["GW_NO_FASTMATH", "GW_NO_CLASSES", "GW_NO_TICKJUMP"])
+def test_parity_with_exact_fast_paths_switched_off(switch, monkeypatch):
+    """The fast forms (FMA remainder, 3-op division, integer decode rule, certainty classes, tick jump) are exact
+    replacements validated at gw_create; with any of them switched off (read at gw_create) the plain forms run and
+    the results must be the same bits.  Step kernel and fused rollout."""
+    import torch
+    monkeypatch.setenv(switch, "1")
+    N, K, D = 2048, 72, 4
+    env, orc = _mk(N, D)
+    dev, dur = action_stream(61, K, N, D)
+    _run(env, orc, dev, dur, reset_every=24)
+    fo, fr, fd = env.rollout(torch.from_numpy(dev[:40]).cuda(), torch.from_numpy(dur[:40]).cuda())
+    for k in range(40):
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all(), k
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")

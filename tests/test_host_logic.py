@@ -66,7 +66,7 @@ def test_fast_paths_validate_for_default_configs(native_lib):
         cfg = _native.default_config(1024, D)
         mx = C.c_int32()
         mask = native_lib.gw_selftest_fastmath(C.byref(cfg), C.byref(mx))
-        assert mask == 15, "D=%d: fast paths %d" % (D, mask)
+        assert mask == 31, "D=%d: fast paths %d" % (D, mask)
         assert mx.value == want_states
     cfg = _native.default_config(16, 4)
     cfg.code_rate, cfg.max_ber = 0.5, 0.11                # integer decode shortcut must switch itself off

@@ -312,8 +312,10 @@ def main():
                          "state_bytes_per_env_step": state_bytes(D),
                          "note": "achieved uses SURVEY 8d's algorithmic bytes (4 B per queue entry appended/popped); "
                                  "the suffix queue encoding never materialises those entries, so measured HBM traffic "
-                                 "(traffic, rocprofv3 PMC, profiles/) is BELOW the algorithmic bytes and the kernel is "
-                                 "bound by f64 dependent-op latency at one wave per SIMD, not by HBM"},
+                                 "(traffic, rocprofv3 PMC, profiles/) is BELOW the algorithmic bytes; by bytes actually moved the "
+                                 "launch runs at ~25% of HBM peak and is bound by latency: one wave per SIMD, every wave in the same "
+                                 "phase (load burst, serial per-env walk, store burst), 63% of wave cycles in s_waitcnt "
+                                 "(profiles/r1_final/SUMMARY.txt)"},
         }
         if roll is not None:
             out["fused_rollout"] = roll

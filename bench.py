@@ -231,7 +231,9 @@ def main():
 
     # ---- secondary: the same K steps as hipGraph replays (reset + 64 gw_step launches captured once) ----------
     graph_sec = None
-    if not args.no_graph and K % RESET_EVERY == 0 and W % RESET_EVERY == 0:
+    # (N = 1 only: stream capture next to a live RCCL communicator -- whose watchdog thread queries events -- is a
+    #  needless risk for a secondary figure)
+    if not args.no_graph and world == 1 and K % RESET_EVERY == 0 and W % RESET_EVERY == 0:
         G = RESET_EVERY
         g_dev = torch.zeros((G, N), dtype=torch.int32, device=dev_t)
         g_dur = torch.zeros((G, N), dtype=torch.int32, device=dev_t)

@@ -194,6 +194,12 @@ def main():
     s1 = env.stats()
     env.check()
 
+    # the job's time is the slowest rank's; taken now so that the secondaries below contain no collective
+    t = torch.tensor([wall], dtype=torch.float64, device=dev_t if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
     # ---- kernel duration --------------------------------------------------------------------------
     # The K launches of the timed region run back-to-back on one stream (the GPU is the bottleneck),
     # so (HIP event at the end - HIP event at the start) / K is the average launch duration including
@@ -201,11 +207,16 @@ def main():
     # (Event pairs around every launch were tried first: each pair adds ~2.5 us of its own.)
     stream_s = ev[0].elapsed_time(ev[1]) * 1e-3
     kern_avg_s = stream_s / K
-    s2 = s1
 
-    # ---- secondary: the same K steps through gw_rollout (one persistent launch per 64 pre-staged steps)
-    roll = None
-    if not args.no_rollout:
+    # ---- secondaries (no collectives inside; a failure is reported in the JSON, it does not cost the headline) ----
+    def guarded(fn):
+        try:
+            return fn()
+        except Exception as exc:
+            return {"error": repr(exc)}
+
+    def secondary_rollout():
+        """The same K steps through gw_rollout: one persistent launch per 64 pre-staged steps."""
         r_obs = torch.empty((RESET_EVERY, N), dtype=torch.int32, device=dev_t)
         r_rew = torch.empty((RESET_EVERY, N), dtype=torch.float32, device=dev_t)
         r_done = torch.empty((RESET_EVERY, N), dtype=torch.uint8, device=dev_t)
@@ -218,22 +229,17 @@ def main():
                 env.rollout(a_dev[lo:hi], a_dur[lo:hi], out=(r_obs[:hi - lo], r_rew[:hi - lo], r_done[:hi - lo]))
         run_rollouts()                                # warm-up
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
         t1 = time.perf_counter()
         run_rollouts()
         torch.cuda.synchronize()
         roll_wall = time.perf_counter() - t1
         env.check()
-        roll = {"env_steps_per_s_this_rank": N * K / roll_wall, "ms_per_step": roll_wall / K * 1e3,
+        return {"env_steps_per_s_this_rank": N * K / roll_wall, "ms_per_step": roll_wall / K * 1e3,
                 "what": "gw_rollout: one persistent launch per %d pre-staged steps (ct_rollout_sfx.hip), same K steps, "
                         "same outputs; not the headline because env.step() is one call per step" % RESET_EVERY}
 
-    # ---- secondary: the same K steps as hipGraph replays (reset + 64 gw_step launches captured once) ----------
-    graph_sec = None
-    # (N = 1 only: stream capture next to a live RCCL communicator -- whose watchdog thread queries events -- is a
-    #  needless risk for a secondary figure)
-    if not args.no_graph and world == 1 and K % RESET_EVERY == 0 and W % RESET_EVERY == 0:
+    def secondary_graph():
+        """The same K gw_step launches replayed from a hipGraph of reset + 64 steps."""
         G = RESET_EVERY
         g_dev = torch.zeros((G, N), dtype=torch.int32, device=dev_t)
         g_dur = torch.zeros((G, N), dtype=torch.int32, device=dev_t)
@@ -252,21 +258,18 @@ def main():
                 graph.replay()
         run_graphs()                                  # warm-up
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
         t2 = time.perf_counter()
         run_graphs()
         torch.cuda.synchronize()
         g_wall = time.perf_counter() - t2
         env.check()
-        graph_sec = {"env_steps_per_s_this_rank": N * K / g_wall, "ms_per_step": g_wall / K * 1e3,
-                     "what": "the same K gw_step launches replayed from a hipGraph of reset + %d steps (launch-bound "
-                             "host loop removed; includes the copy of each chunk's actions into the graph's input buffers)" % G}
+        return {"env_steps_per_s_this_rank": N * K / g_wall, "ms_per_step": g_wall / K * 1e3,
+                "what": "the same K gw_step launches replayed from a hipGraph of reset + %d steps (launch-bound "
+                        "host loop removed; includes the copy of each chunk's actions into the graph's input buffers)" % G}
 
-    # ---- secondary: steady state without resets (SURVEY 8d asks for it separately): after ~0.2 s of simulated
-    #      time the packets have outgrown every window and steps carry no data any more --------------------
-    steady = None
-    if not args.no_steady:
+    def secondary_steady():
+        """Steady state without resets (SURVEY 8d asks for it separately): after ~0.2 s of simulated time the
+        packets have outgrown every window and steps carry no data any more."""
         env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
         n_ss = min(256, K)
         for i in range(W, W + min(64, K)):
@@ -277,14 +280,16 @@ def main():
             env.step(acts[i])
         torch.cuda.synchronize()
         ss_wall = time.perf_counter() - t3
-        steady = {"env_steps_per_s_this_rank": N * n_ss / ss_wall, "ms_per_step": ss_wall / n_ss * 1e3, "steps": n_ss,
-                  "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "
-                          "for any window, so a step is the announcement plus counter ticks"}
+        return {"env_steps_per_s_this_rank": N * n_ss / ss_wall, "ms_per_step": ss_wall / n_ss * 1e3, "steps": n_ss,
+                "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "
+                        "for any window, so a step is the announcement plus counter ticks"}
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev_t if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    roll = guarded(secondary_rollout) if not args.no_rollout else None
+    # graph replay at N = 1 only: stream capture next to a live RCCL communicator (whose watchdog thread queries
+    # events) is a needless risk for a secondary figure
+    graph_sec = (guarded(secondary_graph)
+                 if (not args.no_graph and world == 1 and K % RESET_EVERY == 0 and W % RESET_EVERY == 0) else None)
+    steady = guarded(secondary_steady) if not args.no_steady else None
 
     if rank == 0:
         env_steps = s1["steps"] - s0["steps"]

@@ -103,9 +103,11 @@ typedef struct gw_config {
  * traffic other than counters); they need GW_CFG_EXPLICIT_QUEUE.  Together they replay the reference's
  * test_simple_mac (tests/networking/test_stack.py:134-235). */
 #define GW_CFG_NO_COUNTER_TRAFFIC 4         /* no counter processes: packets come from gw_enqueue only */
-#define GW_CFG_PEER_RECEIVE   8             /* every sender MAC is kept in receive mode (a RECEIVE command re-issued on
-                                               completion, test_stack.py:176-186): data packets decoded at dest[d]
-                                               while it is idle are handed up and counted ("peer_received") */
+#define GW_CFG_PEER_RECEIVE   8             /* `device.receiving = True` on every sender (networking/devices.py:71-111: a
+                                               RECEIVE command re-issued on completion, as test_stack.py:176-186 does by
+                                               hand; SimpleMac side simple_stack.py:435-444,453-461,473-484): data packets
+                                               decoded at dest[d] while it is idle are handed up and counted
+                                               ("peer_received") */
 #define GW_CFG_FLOAT_DURATION 16            /* the assignment duration is passed as a float (test_stack.py:197):
                                                the announcement payload is len(str(float(slots))) bytes */
 

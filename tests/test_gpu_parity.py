@@ -470,3 +470,27 @@ def test_parity_with_exact_fast_paths_switched_off(switch, monkeypatch):
         oo, orr, od = orc.step(dev[k], dur[k])
         assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all(), k
     assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
+
+
+def test_c_abi_error_paths_on_the_gpu():
+    """Misuse through the real handle: NULL buffers, unknown / wrongly sized state fields, unsupported calls."""
+    import ctypes as C
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv, _native as nat
+    env = VecCounterTrafficEnv(256, 4)
+    L, h = env._L, env._h
+    buf = torch.zeros(256, dtype=torch.int32, device="cuda")
+    assert L.gw_step(h, buf.data_ptr(), None, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None) == nat.EINVAL
+    assert L.gw_rollout(h, -1, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), None) == nat.EINVAL
+    out = np.zeros(256, np.float64)
+    assert L.gw_get_state(h, b"no_such_field", out.ctypes.data, out.nbytes) == nat.EFIELD
+    assert L.gw_get_state(h, b"now", out.ctypes.data, out.nbytes - 8) in (nat.EINVAL, nat.EFIELD)
+    assert L.gw_get_state(h, b"peer_received", out.ctypes.data, out.nbytes) == nat.EFIELD    # needs GW_CFG_PEER_RECEIVE
+    assert L.gw_enqueue(h, 0, buf.data_ptr(), None) == nat.EUNSUPPORTED                       # suffix mode
+    assert L.gw_link_info(h, 0, 9, C.byref(C.c_double()), C.byref(C.c_double())) == nat.EINVAL
+    assert b"" != L.gw_last_error()
+    # the handle is still usable afterwards
+    o, r, d, _ = env.step({"device": buf, "duration": buf})
+    assert int(env.get_state("flags").max()) == 0 and o.shape == (256,)
+    env.close()
+    env.close()                                               # idempotent

@@ -165,3 +165,38 @@ def test_oracle_is_clean_under_asan_ubsan():
         pytest.skip("no gcc/libasan")
     out = subprocess.run(["bash", os.path.join(ROOT, "tests", "sanitize_cpu.sh")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "sanitizers: clean" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu(native_lib):
+    """Error convention: every entry returns 0 or a negative GW_E* and leaves a message in
+    gw_last_error(); configuration errors are reported before any device is touched."""
+    from gymwipe_amd import _native as nat
+    L = native_lib
+    h = C.c_void_p()
+    assert L.gw_create(None, C.byref(h)) == nat.EINVAL and b"NULL" in L.gw_last_error()
+    cfg = nat.Config()
+    assert L.gw_config_default(C.byref(cfg), 64, 1) == nat.EINVAL          # observation needs senders 0 and 1
+    assert L.gw_config_default(C.byref(cfg), 64, nat.MAX_DEVICES + 1) == nat.EINVAL
+    for mutate, word in ((lambda c: setattr(c, "num_envs", 0), b"num_envs"),
+                         (lambda c: setattr(c, "abi_version", 99), b"abi_version"),
+                         (lambda c: c.mult.__setitem__(1, 0), b"mult"),
+                         (lambda c: c.dest.__setitem__(0, 7), b"dest"),
+                         (lambda c: setattr(c, "slot", 0.0), b"slot"),
+                         (lambda c: setattr(c, "flags", nat.CFG_PEER_RECEIVE), b"EXPLICIT_QUEUE"),
+                         (lambda c: c.extra_att_db[0].__setitem__(1, 3.0), b"symmetric"),
+                         (lambda c: c.mult.__setitem__(0, 40), b"EXPLICIT_QUEUE")):
+        cfg = nat.default_config(64, 4)
+        mutate(cfg)
+        rc = L.gw_create(C.byref(cfg), C.byref(h))
+        assert rc in (nat.EINVAL, nat.EUNSUPPORTED), (rc, L.gw_last_error())
+        assert word in L.gw_last_error(), L.gw_last_error()
+        assert not h.value
+    # handle-taking entries refuse a NULL handle
+    assert L.gw_step(None, None, None, None, None, None, None) == nat.EINVAL
+    assert L.gw_reset(None, None, None, None) == nat.EINVAL
+    assert L.gw_rollout(None, 1, None, None, None, None, None, None) == nat.EINVAL
+    assert L.gw_enqueue(None, 0, None, None) == nat.EINVAL
+    assert L.gw_pack_feedback(None, 4, None, None, None, None, 0, None) == nat.EINVAL
+    assert L.gw_get_state(None, b"now", None, 0) == nat.EINVAL
+    assert L.gw_destroy(None) == nat.OK                                  # like free(NULL)
+    assert L.gw_selftest_queue(1, 10, 0, 10) == nat.EINVAL

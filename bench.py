@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--devices", type=int, default=4, help="senders per env (D)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample")
     ap.add_argument("--no-gather", action="store_true",
                     help="N>1: skip the end-of-step observation gather (the only exchange of the path: one byte per "
                          "env-step, one RCCL all-gather per 64 steps, overlapped with stepping)")
@@ -331,7 +332,7 @@ def main():
         if steady is not None:
             out["steady_state_no_reset"] = steady
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (the other ranks would idle)
-            out["cpu_baseline"] = cpu_baseline(D)
+            out["cpu_baseline"] = cpu_baseline(D, args.cpu_seconds, min(3.0, args.cpu_seconds / 4))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,35 @@
+"""The driver's contract with bench.py (one JSON line on stdout; keys, types, roofline and cpu_baseline objects),
+checked on a small run -- `-m gpu`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "128", "--warmup", "64",
+                          "--envs", "8192", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+        base = json.load(fh)
+    assert d["metric"] in base["metric"] and d["unit"] == "env-steps/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 128 and d["warmup"] == 64
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 1e6 and abs(d["value"] - 8192 * 128 / (d["ms_per_step"] * 1e-3 * 128)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert r["traffic"] is None or r["traffic"] > 0            # PMC profile on file only for the 65 536-env shapes
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    for sec in ("fused_rollout", "graph_replay", "steady_state_no_reset"):
+        assert "error" not in d[sec], d[sec]

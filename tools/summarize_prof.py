@@ -40,7 +40,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
                 acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print("\n## counters (%s) -- mean per dispatch" % sub)
         for k, cs in acc.items():
-            if "step" not in k and "plant" not in k and "grid" not in k:
+            if not any(w in k for w in ("step", "rollout", "plant", "grid")):
                 continue
             for c, vals in sorted(cs.items()):
                 print("%s  %s: n=%d mean=%.1f" % (k[:60], c, len(vals), sum(vals) / len(vals)))

@@ -1,4 +1,4 @@
-// ct_common.hip.h -- device helpers shared by the step kernels (explicit-ring and run-length).
+// ct_common.hip.h -- device helpers shared by the step kernels (explicit-ring, suffix, fused rollout).
 // Every f64 expression follows the reference's operation order; compile with -ffp-contract=off.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -71,19 +71,6 @@ __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 l
 {
     return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) +
            (v >= 10000000) + (v >= 100000000) + (v >= 1000000000);
-}
-
-
-// reductions over the ACTIVE width of a wave (blocks narrower than 64 leave the upper lanes unborn)
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v, int width = 64)
-{
-    for (int off = width >> 1; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_or(uint32_t v, int width = 64)
-{
-    for (int off = width >> 1; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
-    return v;
 }
 
 

@@ -70,7 +70,7 @@ class VecCounterTrafficEnv(BaseEnv):
         per_env_stats: explicit-queue mode only -- keep per-env event counters (the default mode always
             keeps them in its 32-byte counter record).
         explicit_queue: hold the MAC queues as explicit rings of packet sizes (generic, slower)
-            instead of the default exact run-length encoding of counter traffic.
+            instead of the default exact suffix encoding of counter traffic (gw_queue.h).
         reuse_outputs: return the same output tensors every step (fast path).
         extra_attenuation: custom attenuation models per device pair (the reference's
             AttenuationModelFactory.setCustomModels / JoinedAttenuationModel, physical.py:402-498), reduced to what they

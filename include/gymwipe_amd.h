@@ -30,6 +30,14 @@
  *   gw_received        CounterTrafficInterpreter.receivedValues / getInfo   counter_traffic.py:72,109-112
  *   gw_get_state       attribute reads the reference's tests perform: SimMan.now, sender.counter,
  *                      sender._mac._packetQueue, phy._receivedPower
+ *   gw_delivered       what SimpleRrmDevice.onPacketReceived feeds a custom Interpreter     networking/devices.py:163-168
+ *   gw_enqueue         SimpleNetworkDevice.send -> SimpleMac queue           networking/devices.py:84-86, simple_stack.py:463-471
+ *   gw_rollout         a Python loop over step()
+ *   gw_pack_feedback / gw_unpack_feedback   (multi-GPU exchange format; the reference is single-process)
+ *   gw_plant_*         OdePlant.updateState, SlidingPendulum getters / setMotorVelocity   plants/core.py:38-49,
+ *                      plants/sliding_pendulum.py:57-85   (builder-defined linear plant)
+ *   gw_grid_*          SimMan.runSimulation(seconds) over the benchmark fixture, Position.set
+ *                      tests/test_benchmark.py:20-91, devices/core.py:77-86
  *   gw_destroy         (garbage collection)
  */
 #ifndef GYMWIPE_AMD_H

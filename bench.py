@@ -124,8 +124,9 @@ def main():
     # GW_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
     # host-side collectives); the driver's runs use the default, RCCL with one GPU per rank.
     backend = os.environ.get("GW_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
+    ndev = max(1, torch.cuda.device_count())
+    if backend != "nccl" or local >= ndev:       # rehearsal, or a launcher that shows each rank only its own GPU
+        local = local % ndev
     torch.cuda.set_device(local)
     dev_t = torch.device("cuda", local)
     if world > 1:

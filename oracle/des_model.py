@@ -1049,6 +1049,114 @@ def scenario_simple_mac():
     return counts
 
 
+class Gate:
+    """construction.py:77-111: send() triggers nReceives; a connection is a callback on it."""
+
+    def __init__(self, sim):
+        self.n_receives = Notifier(sim)
+
+    def connect_to(self, gate):
+        self.n_receives.subscribe_callback(gate.send)
+
+    def send(self, obj):
+        self.n_receives.trigger(obj)
+
+
+class Port:
+    """construction.py:114-174."""
+
+    def __init__(self, sim):
+        self.input, self.output = Gate(sim), Gate(sim)
+
+    def bi_connect_with(self, port):
+        self.output.connect_to(port.input)
+        port.output.connect_to(self.input)
+
+
+def scenario_module_ping_pong():
+    """tests/networking/test_construction.py:73-135 -- two modules with ports a and b, connected in a
+    bidirectional cycle, pass a counter around (one time unit per hop, direction reversed at every multiple of
+    ten).  Returns what the reference asserts: (m1.msgVal, m2.msgVal) at t = 20 and the four receive counts of
+    each module at t = 40."""
+    sim = Sim()
+
+    class Mod:
+        def __init__(self):
+            self.ports = {"a": Port(sim), "b": Port(sim)}
+            self.count = {"a": 0, "b": 0}
+            self.val = None
+            sim.process(self.proc("a", "b"))
+            sim.process(self.proc("b", "a"))
+
+        def proc(self, frm, to):
+            while True:
+                msg = yield self.ports[frm].input.n_receives.event
+                self.val = msg
+                self.count[frm] += 1
+                msg += 1
+                yield sim.timeout(1)
+                if msg % 10 == 0:
+                    self.ports[frm].output.send(msg)
+                else:
+                    self.ports[to].output.send(msg)
+
+    m1, m2 = Mod(), Mod()
+    m1.ports["b"].bi_connect_with(m2.ports["b"])
+    m2.ports["a"].bi_connect_with(m1.ports["a"])
+    out = {}
+
+    def simulation():
+        m1.ports["a"].input.send(1)
+        yield sim.timeout(20)
+        out["vals_t20"] = [m1.val, m2.val]
+        yield sim.timeout(20)
+        out["counts_t40"] = [[m.count["a"], m.count["b"]] for m in (m1, m2)]
+    sim.process(simulation())
+    sim.run(50)
+    return out
+
+
+def scenario_gate_listeners():
+    """tests/networking/test_construction.py:137-200 -- GateListener admission (construction.py:221-342): plain
+    methods are callbacks; generator methods are blocking processes, queued or not.  Returns the logs the
+    reference asserts on, for two identical modules."""
+    sim = Sim()
+
+    class Mod:
+        def __init__(self):
+            self.gates = {"aIn": Gate(sim), "bIn": Gate(sim)}
+            self.logs = [[] for _ in range(4)]
+            self.gates["aIn"].n_receives.subscribe_callback(lambda m: self.logs[0].append(m))
+            self.gates["aIn"].n_receives.subscribe_callback(lambda m: self.logs[1].append(m))
+
+            def b_plain(m):
+                self.logs[2].append(m)
+                yield sim.timeout(10)
+
+            def b_queued(m):
+                self.logs[3].append(m)
+                yield sim.timeout(10)
+            self.gates["bIn"].n_receives.subscribe_process(b_plain, blocking=True, queued=False)
+            self.gates["bIn"].n_receives.subscribe_process(b_queued, blocking=True, queued=True)
+
+    mods = (Mod(), Mod())
+    a_ok = True
+    for i in range(3):                       # test_gate_listener_method: callbacks see every message at once
+        for m in mods:
+            m.gates["aIn"].send("msg%d" % i)
+            a_ok = a_ok and m.logs[0] == ["msg%d" % n for n in range(i + 1)]
+
+    def main():                              # test_gate_listener_generator
+        for i in range(3):
+            for m in mods:
+                m.gates["bIn"].send("msg%d" % i)
+                yield sim.timeout(1)
+    sim.process(main())
+    sim.run(40)
+    return {"callbacks_saw_every_message": a_ok,
+            "non_queued": [m.logs[2] for m in mods], "queued": [m.logs[3] for m in mods]}
+
+
 def scenario_notifier_admission():
     """tests/test_simtools.py:60-120 -- instance counts / last values of a
     non-blocking, a blocking and a blocking+queued subscriber."""

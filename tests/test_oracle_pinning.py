@@ -53,6 +53,21 @@ def test_des_notifier_admission_known_answer():
 
 
 # ---- layer 2 (C restatement) against the same known answer -----------------------------------------
+def test_des_module_ping_pong_known_answer():
+    want = GOLD["module_ping_pong"]["asserts"]
+    got = dm.scenario_module_ping_pong()
+    assert got["vals_t20"] == [want["m1_msgVal_at_t20"], want["m2_msgVal_at_t20"]]
+    assert got["counts_t40"] == [[want["receive_count_per_port_at_t40"]] * 2] * 2
+
+
+def test_des_gate_listener_known_answer():
+    want = GOLD["gate_listeners"]["asserts"]
+    got = dm.scenario_gate_listeners()
+    assert got["callbacks_saw_every_message"] is want["callbacks_see_every_message_immediately"]
+    assert got["non_queued"] == [want["non_queued_blocking_log"]] * 2
+    assert got["queued"] == [want["queued_blocking_log"]] * 2
+
+
 def test_c_oracle_counter_traffic_known_answer():
     orc = CtOracle(1, 2)
     center = GOLD["counter_traffic_env"]["observation_center"]

@@ -68,6 +68,42 @@ def test_des_gate_listener_known_answer():
     assert got["queued"] == [want["queued_blocking_log"]] * 2
 
 
+def test_des_notifier_callback_priority_order():
+    """tests/test_simtools.py:16-43: callbacks subscribed with priorities 0, 1, 2 run highest priority first."""
+    n = dm.Notifier(dm.Sim())
+    hist, cbs = [], []
+    for i in range(3, 0, -1):
+        cbs.append(lambda value, i=i: hist.append((i, value)))
+    for prio, c in enumerate(cbs):
+        n.subscribe_callback(c, prio)
+    n.trigger("test1")
+    assert hist == [(i, "test1") for i in range(1, 4)]
+    hist.clear()
+    for c in cbs:
+        n.unsubscribe_callback(c)
+    n.trigger("test2")
+    assert hist == []
+
+
+def test_des_ports_and_packets():
+    """tests/networking/test_construction.py:18-40 (objects cross bidirectionally connected ports) and
+    tests/networking/test_messages.py:6-14 (a packet is as long as its parts)."""
+    sim = dm.Sim()
+    p1, p2 = dm.Port(sim), dm.Port(sim)
+    got1, got2 = [], []
+    p1.input.n_receives.subscribe_callback(got1.append)
+    p2.input.n_receives.subscribe_callback(got2.append)
+    p1.output.connect_to(p2.input)
+    p2.output.connect_to(p1.input)
+    p1.output.send("test message 1")
+    p2.output.send("test message 2")
+    assert got2 == ["test message 1"] and got1 == ["test message 2"]
+    header, payload = dm.Blob("header"), dm.Blob("payload")
+    pkt = dm.Pkt(header, payload)
+    assert pkt.header is header and pkt.payload is payload
+    assert pkt.byte_size == header.byte_size + payload.byte_size == len("header") + len("payload")
+
+
 def test_c_oracle_counter_traffic_known_answer():
     orc = CtOracle(1, 2)
     center = GOLD["counter_traffic_env"]["observation_center"]

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
         if (data_mode && !finish) {
             bool have = true;
             if (len_d == 0) {
-                if (wake < stopw) {
+                if (mult_d != 0u && wake < stopw) {          // mult 0: a silent sender, nothing will ever arrive
                     cur = wake;
                     wake = wake + interval;
                     tau++;

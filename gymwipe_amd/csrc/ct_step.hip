@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 for (;;) {
                     if (rd.len == 0) {                                    // :409-416
                         const double w = wake_d;
-                        if (w < stopw) {
+                        // (a silent sender, mult 0, never signals packet-added: the MAC waits for the timeout)
+                        if (mult_d > 0 && w < stopw) {
                             cur = w;
                             tick_append(rd, base_bytes + ctr_d, mult_d, k);
                             if (ctr_d < bound) ctr_d++;

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 ticks_to(cur, false);
                 for (;;) {
                     if (len_d == 0) {                                     // :409-416
-                        if (wake < stopw) {
+                        // (a silent sender, mult 0, never signals packet-added: the MAC waits for the timeout)
+                        if (mult_d != 0u && wake < stopw) {
                             cur = wake;
                             wake = wake + interval;
                             tau++;

@@ -99,7 +99,7 @@ int validate(const gw_config& c)
     if (c.num_devices < 2 || c.num_devices > GW_MAX_DEVICES)
         return fail(GW_EINVAL, "num_devices must be in [2, %d] (observation uses senders 0 and 1)", GW_MAX_DEVICES);
     for (int i = 0; i < c.num_devices; ++i) {
-        if (c.mult[i] < 1 || c.mult[i] > GW_QUEUE_CAP) return fail(GW_EINVAL, "mult[%d] out of range", i);
+        if (c.mult[i] < 0 || c.mult[i] > GW_QUEUE_CAP) return fail(GW_EINVAL, "mult[%d] out of range", i);   // 0 = a silent sender
         if (c.dest[i] < 0 || c.dest[i] >= c.num_devices) return fail(GW_EINVAL, "dest[%d] out of range", i);
     }
     if (!(c.slot > 0) || !(c.bit_rate > 0) || !(c.code_rate > 0 && c.code_rate <= 1) || !(c.counter_interval > 0))
@@ -262,7 +262,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     k.counter_bound = cfg->counter_bound; k.payload_value = cfg->payload_value;
     k.mac_hdr = cfg->mac_header_bytes; k.net_hdr = cfg->net_header_bytes;
     k.duration_factor = cfg->duration_factor; k.max_duration = cfg->max_duration;
-    for (int i = 0; i < D; ++i) { k.mult[i] = cfg->mult[i]; k.inv16[i] = (65536u + (uint32_t)cfg->mult[i] - 1u) / (uint32_t)cfg->mult[i]; }
+    for (int i = 0; i < D; ++i) { k.mult[i] = cfg->mult[i]; k.inv16[i] = cfg->mult[i] > 0 ? (65536u + (uint32_t)cfg->mult[i] - 1u) / (uint32_t)cfg->mult[i] : 0u; }
     k.no_traffic = (cfg->flags & GW_CFG_NO_COUNTER_TRAFFIC) ? 1 : 0;
     k.peer_receive = (cfg->flags & GW_CFG_PEER_RECEIVE) ? 1 : 0;
     k.float_duration = (cfg->flags & GW_CFG_FLOAT_DURATION) ? 1 : 0;

@@ -13,6 +13,7 @@
 int gw_plant_launch_update(const GwPlantDev& p, const void* now_base, int64_t stride, void* stream);
 int gw_plant_launch_set_input(const GwPlantDev& p, const double* u, const uint8_t* mask, void* stream);
 int gw_plant_launch_init(const GwPlantDev& p, const double* x0, double u0, void* stream);
+int gw_plant_launch_feedback(const GwPlantDev& p, int32_t* obs, float* reward, double* angle_deg, void* stream);
 
 int gw_set_error(int code, const char* fmt, ...);      // gw_api.cpp
 
@@ -153,6 +154,14 @@ int gw_plant_set_input(gw_plant* p, const double* u_dev, const uint8_t* mask_dev
     if (!p || !u_dev) return gw_set_error(GW_EINVAL, "plant/u is NULL");
     PLANT_HIP(hipSetDevice(p->cfg.hip_device), (void)0);
     if (gw_plant_launch_set_input(p->dev, u_dev, mask_dev, stream)) return gw_set_error(GW_EHIP, "plant set_input launch failed");
+    return GW_OK;
+}
+
+int gw_plant_feedback(gw_plant* p, int32_t* obs_dev, float* reward_dev, double* angle_deg_dev, void* stream)
+{
+    if (!p) return gw_set_error(GW_EINVAL, "plant is NULL");
+    PLANT_HIP(hipSetDevice(p->cfg.hip_device), (void)0);
+    if (gw_plant_launch_feedback(p->dev, obs_dev, reward_dev, angle_deg_dev, stream)) return gw_set_error(GW_EHIP, "plant feedback launch failed");
     return GW_OK;
 }
 

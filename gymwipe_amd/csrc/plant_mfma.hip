@@ -90,6 +90,24 @@ int gw_plant_launch_update(const GwPlantDev& p, const void* now_base, int64_t st
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
+// InvertedPendulumInterpreter (envs/inverted_pendulum.py:27-57): observation int(degrees(angle)), reward
+// float(abs(180 - degrees(angle))); math.degrees(x) is x * (180 / pi) in CPython
+__global__ void plant_feedback_kernel(GwPlantDev p, int32_t* __restrict__ obs, float* __restrict__ reward, double* __restrict__ angle_deg)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.N) return;
+    const double deg = p.x[e * 4 + 2] * (180.0 / 3.141592653589793);
+    if (obs) obs[e] = (int32_t)deg;                       // int(): truncation towards zero
+    if (reward) reward[e] = (float)fabs(180.0 - deg);
+    if (angle_deg) angle_deg[e] = deg;
+}
+
+int gw_plant_launch_feedback(const GwPlantDev& p, int32_t* obs, float* reward, double* angle_deg, void* stream)
+{
+    hipLaunchKernelGGL(plant_feedback_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, obs, reward, angle_deg);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
 int gw_plant_launch_set_input(const GwPlantDev& p, const double* u, const uint8_t* mask, void* stream)
 {
     hipLaunchKernelGGL(plant_set_input_kernel, dim3((unsigned)((p.N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, u, mask);

@@ -5,6 +5,7 @@ Environment registry with the reference's ids (gymwipe/envs/__init__.py:6-14).
 """
 from .core import BaseEnv, Interpreter, VecInterpreter, VecPayload       # noqa: F401
 from .counter_traffic import CounterTrafficEnv, VecCounterTrafficEnv     # noqa: F401
+from .inverted_pendulum import InvertedPendulumEnv, VecInvertedPendulumEnv   # noqa: F401
 
 registry = {}
 
@@ -24,8 +25,10 @@ def make(id, **kwargs):
 
 register(id='CounterTraffic-v0', entry_point=CounterTrafficEnv)
 register(id='VecCounterTraffic-v0', entry_point=VecCounterTrafficEnv)
-# 'InvertedPendulum-v0' of the reference cannot be constructed there
-# (simtools.py:39-42 self-recursive setter) and is out of this round's scope.
+# 'InvertedPendulum-v0' of the reference cannot be constructed there (simtools.py:39-42 self-recursive setter);
+# here it is the env as shipped (open loop) over a builder-defined linear plant: see inverted_pendulum.py
+register(id='InvertedPendulum-v0', entry_point=InvertedPendulumEnv)
+register(id='VecInvertedPendulum-v0', entry_point=VecInvertedPendulumEnv)
 
 try:  # pragma: no cover - gym is not installed in the build image
     from gym.envs.registration import register as _gym_register

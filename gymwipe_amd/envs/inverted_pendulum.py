@@ -1,0 +1,106 @@
+"""
+Host-side mirror of gymwipe/envs/inverted_pendulum.py for N environments on one MI355X.
+
+The reference env assigns the frequency band to an angle sensor (device index 0) and a PID controller
+(index 1) of a sliding pendulum and reads observation and reward straight off the plant
+(``InvertedPendulumInterpreter``, envs/inverted_pendulum.py:27-57):
+
+    observation = int(degrees(angle))        reward = float(abs(180 - degrees(angle)))       done = False
+
+What this class keeps of it, and what it cannot:
+
+* the gym surface (action space of two devices x 20 durations, ``observation_space = Discrete(180)``,
+  ``step`` = assign, run to the end of the assignment, read the plant) and the interpreter's formulas, evaluated on
+  the GPU (``gw_plant_feedback``);
+* the network of the env AS SHIPPED: the sensor samples every millisecond (sliding_pendulum.py:116-135), nobody sets
+  ``receiving``, so the controller's angle stays 0, its control loop never sends (control/inverted_pendulum.py:52-69)
+  and the loop is open -- a sender with multiplicity 1 and a silent one (multiplicity 0) on the CounterTraffic step
+  kernel, controller at (0, -1), RRM at (0, 1), sensor at the wagon's start (0, 0) (envs/inverted_pendulum.py:75-93);
+* the plant is BUILDER-DEFINED: the reference integrates an ODE rigid-body world (py3ode, absent) inside an env that
+  cannot even be constructed (simtools.py:39-42); here ``VecLinearPlant`` advances a linear model ``x <- A x + B u`` to the
+  env clock on the f64 matrix cores.  Parity with the reference is therefore unpinned for this env; the sensor's packet
+  sizes follow the counter-traffic rule (25 + counter bytes), not the reference's ``Transmittable(2, angle)``, whose
+  byte size is the angle itself.
+"""
+import ctypes as C
+
+from .. import _native as nat
+from .. import spaces
+from ..plants import VecLinearPlant
+from .core import BaseEnv
+from .counter_traffic import VecCounterTrafficEnv
+
+
+class VecInvertedPendulumEnv(BaseEnv):
+    SENSOR, CONTROLLER = 0, 1                              # deviceIndexToMacDict, envs/inverted_pendulum.py:86-89
+    SAMPLE_INTERVAL = 0.001                                # :79
+
+    _scalar_api = False
+
+    def __init__(self, num_envs, device="cuda:0", plant=None):
+        import torch
+        self._torch = torch
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        BaseEnv.__init__(self, 2)                          # deviceCount=2, :70
+        self.observation_space = spaces.Discrete(180)      # :73
+        self.network = VecCounterTrafficEnv(self.num_envs, 2, device=self.device,
+                                            positions=[(0.0, 0.0), (0.0, -1.0)], rrm_position=(0.0, 1.0),
+                                            multiplicity=[1, 0], dest=[1, 0])
+        self.plant = plant if plant is not None else VecLinearPlant(self.num_envs, device=self.device)
+        base, stride = C.c_void_p(), C.c_int64()
+        nat.check(self.network._L.gw_now_ptr(self.network._h, C.byref(base), C.byref(stride)))
+        self._now = (base.value, stride.value)             # the env clock, read by the plant kernel in place
+        n = self.num_envs
+        self._obs = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._angle = torch.empty(n, dtype=torch.float64, device=self.device)
+        self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+
+    def _feedback(self):
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            nat.check(self.plant._L.gw_plant_feedback(self.plant._h, self._obs.data_ptr(), self._rew.data_ptr(),
+                                                      self._angle.data_ptr(),
+                                                      torch.cuda.current_stream(self.device).cuda_stream))
+        return self._obs, self._rew, self._done, {"Sensor angle": self._angle}
+
+    def reset(self):
+        """envs/inverted_pendulum.py:95-99: returns an observation, resets nothing."""
+        return self._feedback()[0]
+
+    def step(self, action):
+        """:101-113 for every env: assign the band, run to the end of the assignment, read the plant."""
+        self.network.step(action)
+        self.plant.updateState(self._now)                  # OdePlant.updateState, lazily, to the new env clock
+        return self._feedback()
+
+    def render(self, mode="human", close=False):           # :115-116
+        pass
+
+    def close(self):
+        self.network.close()
+        self.plant.close()
+
+
+class InvertedPendulumEnv(VecInvertedPendulumEnv):
+    """N = 1 with the reference's scalar surface: ``step({"device": int, "duration": int}) ->
+    (int, float, bool, {"Sensor angle": float})``, ``AssertionError`` on an action outside the action space."""
+    _scalar_api = True
+
+    def __init__(self, device="cuda:0"):
+        VecInvertedPendulumEnv.__init__(self, 1, device=device)
+        self._act = self._torch.zeros((2, 1), dtype=self._torch.int32, device=self.device)
+
+    def _scalars(self, fb):
+        obs, rew, done, info = fb
+        return int(obs.item()), float(rew.item()), bool(done.item()), {"Sensor angle": float(info["Sensor angle"].item())}
+
+    def reset(self):
+        return self._scalars(self._feedback())[0]
+
+    def step(self, action):
+        assert self.action_space.contains(action)          # :102
+        self._act[0, 0] = int(action["device"])
+        self._act[1, 0] = int(action["duration"])
+        return self._scalars(VecInvertedPendulumEnv.step(self, {"device": self._act[0], "duration": self._act[1]}))

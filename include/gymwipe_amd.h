@@ -78,7 +78,7 @@ typedef struct gw_config {
     int32_t num_devices;                    /* D senders; radio index D is the RRM */
     int32_t flags;                          /* GW_CFG_* */
     double  pos[GW_MAX_RADIOS][2];          /* metres; [D] = RRM */
-    int32_t mult[GW_MAX_DEVICES];           /* packets per counter tick (packetMultiplicity) */
+    int32_t mult[GW_MAX_DEVICES];           /* packets per counter tick (packetMultiplicity); 0 = a sender with nothing to send */
     int32_t dest[GW_MAX_DEVICES];           /* destination sender index */
     double  slot;                           /* TIME_SLOT_LENGTH 1e-6 s */
     double  frequency;                      /* 2.4e9 Hz */
@@ -228,6 +228,9 @@ int gw_plant_destroy(gw_plant* p);
 int gw_plant_update(gw_plant* p, const void* now_dev, int64_t stride_bytes, void* stream);
 /* u[e] <- u_dev[e] where mask_dev is NULL or mask_dev[e] != 0 (setMotorVelocity; the caller updates first) */
 int gw_plant_set_input(gw_plant* p, const double* u_dev, const uint8_t* mask_dev, void* stream);
+/* InvertedPendulumInterpreter (envs/inverted_pendulum.py:27-57) for every plant: obs = int(degrees(angle)),
+ * reward = float(abs(180 - degrees(angle))), optionally the angle in degrees ("Sensor angle").  Any pointer may be NULL. */
+int gw_plant_feedback(gw_plant* p, int32_t* obs_dev, float* reward_dev, double* angle_deg_dev, void* stream);
 /* device pointer to the state, double[N][4] (row e = {pos, vel, angle, rate}); valid until gw_plant_destroy */
 int gw_plant_state_ptr(gw_plant* p, double** x_dev);
 /* host copies for tests: "x" f64[N][4] | "u" f64[N] | "t_last" f64[N] | "substeps" u64[N] */

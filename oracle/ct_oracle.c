@@ -322,7 +322,8 @@ static void step_one(cto_vec* v, int64_t e, int d, int duration,
         for (;;) {
             if (v->qlen[kd] == 0) {                          /* :409-416 */
                 double w = v->wake[kd];
-                if (w < stopw) { cur = w; tick(&c, d); }
+                /* a silent sender (mult 0) never signals packet-added: the MAC waits for the window timeout */
+                if (cf->mult[d] > 0 && w < stopw) { cur = w; tick(&c, d); }
                 else break;
             }
             uint32_t s = ring[v->qhead[kd]];

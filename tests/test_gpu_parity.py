@@ -494,3 +494,21 @@ def test_c_abi_error_paths_on_the_gpu():
     assert int(env.get_state("flags").max()) == 0 and o.shape == (256,)
     env.close()
     env.close()                                               # idempotent
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+def test_parity_with_silent_senders(explicit):
+    """mult = 0: senders that never enqueue anything (their windows stay empty until the timeout); step kernel in
+    both queue modes and the fused rollout."""
+    import torch
+    N, K, D = 1024, 64, 4
+    env, orc = _mk(N, D, explicit=explicit, multiplicity=[2, 0, 1, 0])
+    dev, dur = action_stream(71, K, N, D)
+    _run(env, orc, dev, dur, reset_every=25)
+    if not explicit:
+        fo, fr, fd = env.rollout(torch.from_numpy(dev[:40]).cuda(), torch.from_numpy(dur[:40]).cuda())
+        for k in range(40):
+            oo, orr, od = orc.step(dev[k], dur[k])
+            assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all(), k
+        assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
+    assert (env.get_state("qlen")[:, 1] == 0).all() and (env.get_state("qlen")[:, 3] == 0).all()

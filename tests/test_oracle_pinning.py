@@ -165,6 +165,13 @@ def test_c_oracle_equals_event_driven_restatement_joined_attenuation():
     _compare(3, 90, 7, 25, True, extra_att={(0, 3): 3.0, (1, 3): 7.5, (0, 1): 1.25})
 
 
+def test_c_oracle_equals_event_driven_restatement_silent_sender():
+    # mult 0: a sender whose counter process enqueues nothing (the reference's pendulum controller is such a
+    # device as shipped); assigned windows stay empty until they time out
+    _compare(3, 70, 8, 20, True, mult=[1, 0, 3])
+    _compare(2, 40, 9, None, True, mult=[0, 2])
+
+
 # ---- secondary cross-check against SURVEY.md's probe values (NOT reference output) ----------------
 def test_secondary_survey_probe_values():
     p = GOLD["survey_probe_secondary"]

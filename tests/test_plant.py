@@ -85,3 +85,43 @@ def test_plant_follows_the_env_clock():
     assert (plant.get_state("t_last") == now).all()
     sub = plant.get_state("substeps").astype(np.int64)
     assert (np.abs(sub - now / 1e-3) <= 10).all()                  # one rounding per update, 10 updates
+
+
+@pytest.mark.gpu
+def test_inverted_pendulum_env_surface_and_interpreter_formulas():
+    """envs/inverted_pendulum.py: gym surface, and observation / reward exactly as InvertedPendulumInterpreter
+    computes them from the plant (:27-57) -- int(degrees(angle)), float(abs(180 - degrees(angle))) -- while the plant
+    follows the env clock.  The network is the env as shipped: the sensor's queue fills and drains, the controller
+    never has anything to send."""
+    import math
+    import torch
+    from gymwipe_amd import VecInvertedPendulumEnv, InvertedPendulumEnv, spaces
+    N = 512
+    env = VecInvertedPendulumEnv(N)
+    assert env.action_space.contains({"device": 1, "duration": 19}) and isinstance(env.observation_space, spaces.Discrete)
+    assert env.observation_space.n == 180
+    obs0 = env.reset()
+    x0 = env.plant.state()
+    assert (obs0.cpu().numpy() == np.array([int(math.degrees(a)) for a in x0[:, 2]])).all()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for k in range(40):
+        act = {"device": torch.randint(0, 2, (N,), dtype=torch.int32, device="cuda", generator=g),
+               "duration": torch.randint(0, 20, (N,), dtype=torch.int32, device="cuda", generator=g)}
+        obs, rew, done, info = env.step(act)
+    now = env.network.get_state("now")
+    x = env.plant.state()
+    np.testing.assert_allclose(env.plant.get_state("t_last"), np.floor(now / env.plant.config.dt + 1e-9) * env.plant.config.dt,
+                               rtol=0, atol=env.plant.config.dt)            # the plant has been advanced to the env clock
+    deg = np.array([math.degrees(a) for a in x[:, 2]])
+    assert (obs.cpu().numpy() == deg.astype(np.int64)).all()                 # int(): truncation towards zero
+    np.testing.assert_allclose(rew.cpu().numpy(), np.abs(180.0 - deg).astype(np.float32), rtol=1e-7)
+    np.testing.assert_allclose(info["Sensor angle"].cpu().numpy(), deg, rtol=1e-15)
+    assert not done.any()
+    q = env.network.get_state("qlen")
+    assert (q[:, 1] == 0).all() and q[:, 0].max() > 0                        # silent controller, busy sensor
+    assert int(env.network.get_state("flags").max()) & 3 == 0
+    one = InvertedPendulumEnv()                                              # the scalar surface of the reference
+    o, r, d, i = one.step({"device": 0, "duration": 5})
+    assert isinstance(o, int) and isinstance(r, float) and d is False and isinstance(i["Sensor angle"], float)
+    with pytest.raises(AssertionError):
+        one.step({"device": 2, "duration": 5})

@@ -183,7 +183,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu(native_lib):
     assert L.gw_config_default(C.byref(cfg), 64, nat.MAX_DEVICES + 1) == nat.EINVAL
     for mutate, word in ((lambda c: setattr(c, "num_envs", 0), b"num_envs"),
                          (lambda c: setattr(c, "abi_version", 99), b"abi_version"),
-                         (lambda c: c.mult.__setitem__(1, 0), b"mult"),
+                         (lambda c: c.mult.__setitem__(1, -1), b"mult"),
                          (lambda c: c.dest.__setitem__(0, 7), b"dest"),
                          (lambda c: setattr(c, "slot", 0.0), b"slot"),
                          (lambda c: setattr(c, "flags", nat.CFG_PEER_RECEIVE), b"EXPLICIT_QUEUE"),

@@ -8,29 +8,26 @@ import gymwipe_amd
 from gymwipe_amd import _native as nat
 
 N, K, W = int(os.environ.get("N", 32768)), 256, 32
-env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=2)
-plant = gymwipe_amd.VecLinearPlant(N)
-base, stride = C.c_void_p(), C.c_int64()
-nat.check(env._L.gw_now_ptr(env._h, C.byref(base), C.byref(stride)))
-now = (base.value, stride.value)
+penv = gymwipe_amd.VecInvertedPendulumEnv(N)             # band-assignment step + plant advance + interpreter feedback
+env, plant = penv.network, penv.plant
 g = torch.Generator(device="cuda"); g.manual_seed(7)
 dev = torch.randint(0, 2, (W + K, N), dtype=torch.int32, device="cuda", generator=g)
 dur = torch.randint(0, 20, (W + K, N), dtype=torch.int32, device="cuda", generator=g)
 acts = [{"device": dev[i], "duration": dur[i]} for i in range(W + K)]
 env.reset()
 for i in range(W):
-    env.step(acts[i]); plant.updateState(now)
+    penv.step(acts[i])
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0 = time.perf_counter(); e0.record()
 for i in range(W, W + K):
     if i % 64 == 0:
         env.reset()
-    env.step(acts[i]); plant.updateState(now)
+    penv.step(acts[i])
 e1.record(); torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 sub = int(plant.get_state("substeps").sum())
 # useful flops: 40 per plant substep (2*4*4 + 2*4); issued MFMA flops: 2 MFMAs x 2*16*16*4 per 16 envs per candidate group
-print(json.dumps({"workload": "pendulum band-assign env (builder-defined): %d envs, CounterTraffic D=2 step + linear plant advance" % N,
+print(json.dumps({"workload": "pendulum band-assign env (builder-defined): %d envs, VecInvertedPendulumEnv.step = band-assignment step (sensor + silent controller) + linear plant advance + interpreter feedback" % N,
                   "env_steps_per_s": N * K / wall, "ms_per_step": wall / K * 1e3, "stream_ms_per_step": e0.elapsed_time(e1) / K,
                   "plant_substeps_total": sub, "useful_plant_gflops": 40.0 * sub / (W + K) * K / wall / 1e9}))

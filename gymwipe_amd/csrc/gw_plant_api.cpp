@@ -10,7 +10,8 @@
 #include <vector>
 
 
-int gw_plant_launch_update(const GwPlantDev& p, const void* now_base, int64_t stride, void* stream);
+int gw_plant_launch_update(const GwPlantDev& p, const void* now_base, int64_t stride, int32_t* obs, float* reward, double* angle_deg,
+                           void* stream);
 int gw_plant_launch_set_input(const GwPlantDev& p, const double* u, const uint8_t* mask, void* stream);
 int gw_plant_launch_init(const GwPlantDev& p, const double* x0, double u0, void* stream);
 int gw_plant_launch_feedback(const GwPlantDev& p, int32_t* obs, float* reward, double* angle_deg, void* stream);
@@ -145,7 +146,18 @@ int gw_plant_update(gw_plant* p, const void* now_dev, int64_t stride_bytes, void
     if (!p || !now_dev) return gw_set_error(GW_EINVAL, "plant/now is NULL");
     if (stride_bytes < 8 || (stride_bytes & 7)) return gw_set_error(GW_EINVAL, "stride_bytes must be a multiple of 8");
     PLANT_HIP(hipSetDevice(p->cfg.hip_device), (void)0);
-    if (gw_plant_launch_update(p->dev, now_dev, stride_bytes, stream)) return gw_set_error(GW_EHIP, "plant update launch failed");
+    if (gw_plant_launch_update(p->dev, now_dev, stride_bytes, nullptr, nullptr, nullptr, stream)) return gw_set_error(GW_EHIP, "plant update launch failed");
+    return GW_OK;
+}
+
+int gw_plant_update_feedback(gw_plant* p, const void* now_dev, int64_t stride_bytes, int32_t* obs_dev, float* reward_dev,
+                             double* angle_deg_dev, void* stream)
+{
+    if (!p || !now_dev) return gw_set_error(GW_EINVAL, "plant/now is NULL");
+    if (stride_bytes < 8 || (stride_bytes & 7)) return gw_set_error(GW_EINVAL, "stride_bytes must be a multiple of 8");
+    PLANT_HIP(hipSetDevice(p->cfg.hip_device), (void)0);
+    if (gw_plant_launch_update(p->dev, now_dev, stride_bytes, obs_dev, reward_dev, angle_deg_dev, stream))
+        return gw_set_error(GW_EHIP, "plant update launch failed");
     return GW_OK;
 }
 

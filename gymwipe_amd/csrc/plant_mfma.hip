@@ -22,7 +22,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__global__ __launch_bounds__(64) void plant_update_kernel(GwPlantDev p, const char* __restrict__ now_base, int64_t stride)
+__global__ __launch_bounds__(64) void plant_update_kernel(GwPlantDev p, const char* __restrict__ now_base, int64_t stride,
+                                                           int32_t* __restrict__ obs, float* __restrict__ reward,
+                                                           double* __restrict__ angle_deg)
 {
     const int lane = threadIdx.x;
     const int g = lane >> 4, col = lane & 15;
@@ -61,6 +63,12 @@ __global__ __launch_bounds__(64) void plant_update_kernel(GwPlantDev p, const ch
             p.x[e * 4 + g] = xg;
             if (g == 0) { p.t_last[e] = now; p.nsub[e] += (unsigned long long)n_total; }
         }
+        if (live && g == 2) {                                        // this lane holds the angle: interpreter feedback
+            const double deg = xg * (180.0 / 3.141592653589793);     // (envs/inverted_pendulum.py:27-57), fused
+            if (obs) obs[e] = (int32_t)deg;
+            if (reward) reward[e] = (float)fabs(180.0 - deg);
+            if (angle_deg) angle_deg[e] = deg;
+        }
     }
 }
 
@@ -82,11 +90,13 @@ __global__ void plant_init_kernel(GwPlantDev p, double x0, double x1, double x2,
 
 } // namespace
 
-int gw_plant_launch_update(const GwPlantDev& p, const void* now_base, int64_t stride, void* stream)
+int gw_plant_launch_update(const GwPlantDev& p, const void* now_base, int64_t stride, int32_t* obs, float* reward, double* angle_deg,
+                           void* stream)
 {
     const int64_t tiles = (p.N + 15) >> 4;
     const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);   // >> 256 CUs; grid-stride over the rest
-    hipLaunchKernelGGL(plant_update_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, p, (const char*)now_base, stride);
+    hipLaunchKernelGGL(plant_update_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, p, (const char*)now_base, stride,
+                       obs, reward, angle_deg);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 

@@ -71,9 +71,13 @@ class VecInvertedPendulumEnv(BaseEnv):
 
     def step(self, action):
         """:101-113 for every env: assign the band, run to the end of the assignment, read the plant."""
+        torch = self._torch
         self.network.step(action)
-        self.plant.updateState(self._now)                  # OdePlant.updateState, lazily, to the new env clock
-        return self._feedback()
+        with torch.cuda.device(self.device):               # OdePlant.updateState to the new env clock + the interpreter's
+            nat.check(self.plant._L.gw_plant_update_feedback(    # reading of the plant, one launch
+                self.plant._h, self._now[0], self._now[1], self._obs.data_ptr(), self._rew.data_ptr(),
+                self._angle.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+        return self._obs, self._rew, self._done, {"Sensor angle": self._angle}
 
     def render(self, mode="human", close=False):           # :115-116
         pass

@@ -231,6 +231,9 @@ int gw_plant_set_input(gw_plant* p, const double* u_dev, const uint8_t* mask_dev
 /* InvertedPendulumInterpreter (envs/inverted_pendulum.py:27-57) for every plant: obs = int(degrees(angle)),
  * reward = float(abs(180 - degrees(angle))), optionally the angle in degrees ("Sensor angle").  Any pointer may be NULL. */
 int gw_plant_feedback(gw_plant* p, int32_t* obs_dev, float* reward_dev, double* angle_deg_dev, void* stream);
+/* gw_plant_update and gw_plant_feedback in one launch (what an env.step() of the pendulum env needs after the network step) */
+int gw_plant_update_feedback(gw_plant* p, const void* now_dev, int64_t stride_bytes, int32_t* obs_dev, float* reward_dev,
+                             double* angle_deg_dev, void* stream);
 /* device pointer to the state, double[N][4] (row e = {pos, vel, angle, rate}); valid until gw_plant_destroy */
 int gw_plant_state_ptr(gw_plant* p, double** x_dev);
 /* host copies for tests: "x" f64[N][4] | "u" f64[N] | "t_last" f64[N] | "substeps" u64[N] */

@@ -35,3 +35,17 @@ def test_gpu_resident_dqn_loop_runs():
     st = env.check()                                           # every sampled action was inside the action space
     assert st["steps"] == 24 * 512 and st["bad_actions"] == 0
     assert agent.m_len == min(24 * 512, agent.cap)
+
+
+@pytest.mark.gpu
+def test_quickstart_example_runs():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py")], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "scalar env: (65538, -2.0, False" in out.stdout and "(65536, 2.0, False" in out.stdout   # the reference's known answer
+    for word in ("vectorised:", "rollout:", "custom interpreter:", "pendulum:", "grid:"):
+        assert word in out.stdout

@@ -61,6 +61,7 @@ class Config(C.Structure):
         ("duration_factor", C.c_int32),
         ("max_duration", C.c_int32),
         ("extra_att_db", (C.c_double * MAX_RADIOS) * MAX_RADIOS),
+        ("start_time", C.c_double),
     ]
 
 

@@ -274,8 +274,8 @@ __global__ void ct_init_kernel(GwState st)
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     const int D = st.cst->D, R = st.cst->R;
-    st.now[e] = 0.0;
-    st.wake[e] = st.cst->no_traffic ? (double)INFINITY : 0.0;
+    st.now[e] = st.cst->start_time;
+    st.wake[e] = st.cst->no_traffic ? (double)INFINITY : st.cst->start_time;
     st.counter[e] = 1u;
     st.rvmask[e] = 0u;
     st.last_abs[e] = 0;

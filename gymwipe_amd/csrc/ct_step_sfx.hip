@@ -460,7 +460,7 @@ __global__ void ct_init_sfx_kernel(GwState st)
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint32_t)st.N) return;
     const uint32_t o16 = e << 4;
-    st_(st.tw, o16, make_double2(0.0, 0.0));
+    st_(st.tw, o16, make_double2(st.cst->start_time, st.cst->start_time));
     st_(st.tk, o16, make_uint4(0u, 1u, 0u, 1u));
     st_(st.ip, o16, make_uint4(0u, 1u, 0u, 0u));
     for (int b = 0; b < st.RB; ++b) st.qb[e * (uint32_t)st.RB + b] = 0;

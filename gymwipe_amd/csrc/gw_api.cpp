@@ -117,6 +117,7 @@ int validate(const gw_config& c)
         for (int b = 0; b <= c.num_devices; ++b)
             if (!(c.extra_att_db[a][b] == c.extra_att_db[b][a]) || (a == b && c.extra_att_db[a][b] != 0.0))
                 return fail(GW_EINVAL, "extra_att_db must be symmetric with a zero diagonal (pair %d,%d)", a, b);
+    if (!(c.start_time >= 0.0) || !(c.start_time < 1e12)) return fail(GW_EINVAL, "start_time out of range");
     if ((int64_t)c.max_duration * c.duration_factor > 100000000)
         return fail(GW_EINVAL, "max_duration*duration_factor too large");
     return GW_OK;
@@ -263,6 +264,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     k.mac_hdr = cfg->mac_header_bytes; k.net_hdr = cfg->net_header_bytes;
     k.duration_factor = cfg->duration_factor; k.max_duration = cfg->max_duration;
     for (int i = 0; i < D; ++i) { k.mult[i] = cfg->mult[i]; k.inv16[i] = cfg->mult[i] > 0 ? (65536u + (uint32_t)cfg->mult[i] - 1u) / (uint32_t)cfg->mult[i] : 0u; }
+    k.start_time = cfg->start_time;
     k.no_traffic = (cfg->flags & GW_CFG_NO_COUNTER_TRAFFIC) ? 1 : 0;
     k.peer_receive = (cfg->flags & GW_CFG_PEER_RECEIVE) ? 1 : 0;
     k.float_duration = (cfg->flags & GW_CFG_FLOAT_DURATION) ? 1 : 0;

@@ -26,6 +26,7 @@ struct GwDevConst {
     double  rcp_data_rate;              // RN(1/data_rate)
     double  cls_limit;                  // decode-certainty classes are valid for t < cls_limit
     int32_t fast_fmod, fast_div, fast_decide, idem_states;
+    double  start_time;                 // simulated time at creation (test hook; the reference starts at 0)
     int32_t fast_ticks;                 // gw_tick_jump validated for counter_interval
     double  inv_interval;               // RN(1/counter_interval)
     int32_t no_traffic, peer_receive, float_duration;   // GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION

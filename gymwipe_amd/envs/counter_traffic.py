@@ -90,7 +90,8 @@ class VecCounterTrafficEnv(BaseEnv):
     def __init__(self, num_envs, num_devices=2, device="cuda:0", positions=None,
                  multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
                  reuse_outputs=True, explicit_queue=False, counter_bound=None, interpreter=None,
-                 counter_traffic=True, peer_receive=False, float_duration=False, extra_attenuation=None):
+                 counter_traffic=True, peer_receive=False, float_duration=False, extra_attenuation=None,
+                 start_time=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -126,6 +127,8 @@ class VecCounterTrafficEnv(BaseEnv):
                                      for a in range(D + 1) for b in range(a + 1, D + 1)}
             for (a, b), db in extra_attenuation.items():
                 cfg.extra_att_db[a][b] = cfg.extra_att_db[b][a] = float(db)
+        if start_time is not None:             # test hook: simulated time at creation (the reference starts at 0)
+            cfg.start_time = float(start_time)
         if per_env_stats:
             cfg.flags |= nat.CFG_PER_ENV_STATS
         if explicit_queue:

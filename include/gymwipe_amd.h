@@ -100,6 +100,10 @@ typedef struct gw_config {
      * their attenuations in dB, which the joined model adds to the free-space term (sum() over [FSPL, custom...]).
      * Must be symmetric; 0 = the pair keeps the plain FSPL model. */
     double  extra_att_db[GW_MAX_RADIOS][GW_MAX_RADIOS];
+    /* Simulated time at creation (the reference always starts at 0: SimMan.init).  A test hook: the clock and the first
+     * counter tick start here, which puts the f64 arithmetic of the step (slot remainders, tick sums, decode sums) into
+     * the coarser binades a run reaches only after ~10^8 steps, and past the limits of the validated fast paths. */
+    double  start_time;
 } gw_config;
 
 #define GW_CFG_PER_ENV_STATS  1             /* explicit-queue mode only: keep per-env event counters (the default

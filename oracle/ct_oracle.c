@@ -176,9 +176,9 @@ cto_vec* cto_create(const cto_config* cfg, int64_t n)
     ALLOC(v->n_pop, n);     ALLOC(v->n_drop, n);
 #undef ALLOC
     for (int64_t e = 0; e < n; ++e) {
-        v->now[e] = 0.0;
+        v->now[e] = cfg->start_time;
         for (int i = 0; i < D; ++i) {
-            v->wake[e * D + i] = 0.0;            /* first tick at t = 0 */
+            v->wake[e * D + i] = cfg->start_time; /* first tick at t = 0 (at creation) */
             v->counter[e * D + i] = 1;           /* counter_traffic.py:48 */
         }
         for (int r = 0; r < R; ++r) v->rx[e * R + r] = v->thermal;

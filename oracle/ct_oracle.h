@@ -49,6 +49,7 @@ typedef struct cto_config {
     /* sum of the custom attenuation models of a device pair, dB (JoinedAttenuationModel, physical.py:402-457);
        0 = plain FSPL.  Symmetric. */
     double  extra_att_db[CTO_MAX_RADIOS][CTO_MAX_RADIOS];
+    double  start_time;                      /* simulated time at creation (test hook; the reference starts at 0) */
 } cto_config;
 
 typedef struct cto_vec cto_vec;

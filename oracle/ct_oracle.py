@@ -43,6 +43,7 @@ class Config(C.Structure):
         ("duration_factor", C.c_int32),
         ("max_duration", C.c_int32),
         ("extra_att_db", (C.c_double * MAX_RADIOS) * MAX_RADIOS),
+        ("start_time", C.c_double),
     ]
 
 
@@ -87,7 +88,7 @@ def lib():
     return _lib
 
 
-def default_config(num_devices, positions=None, mult=None, dest=None, rrm_pos=None, extra_att=None):
+def default_config(num_devices, positions=None, mult=None, dest=None, rrm_pos=None, extra_att=None, start_time=None):
     cfg = Config()
     if lib().cto_config_default(C.byref(cfg), num_devices) != 0:
         raise ValueError("num_devices out of range")
@@ -103,6 +104,8 @@ def default_config(num_devices, positions=None, mult=None, dest=None, rrm_pos=No
     if dest is not None:
         for i, m in enumerate(dest):
             cfg.dest[i] = int(m)
+    if start_time is not None:
+        cfg.start_time = float(start_time)
     if extra_att is not None:              # {(a, b): dB}, radio index D = the RRM; applied to both directions
         for (a, b), db in extra_att.items():
             cfg.extra_att_db[a][b] = cfg.extra_att_db[b][a] = float(db)

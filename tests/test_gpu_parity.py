@@ -27,7 +27,7 @@ def _mk(num_envs, D, explicit=False, counter_bound=None, **kw):
         pos = [tuple(env.config.pos[i]) for i in range(D + 1)]
         ea = {(a, b): ea(a, b, pos[a], pos[b]) for a in range(D + 1) for b in range(a + 1, D + 1)}
     cfg = default_config(D, positions=kw.get("positions"), mult=kw.get("multiplicity"),
-                         rrm_pos=kw.get("rrm_position"), extra_att=ea)
+                         rrm_pos=kw.get("rrm_position"), extra_att=ea, start_time=kw.get("start_time"))
     if counter_bound is not None:
         cfg.counter_bound = counter_bound
     orc = CtOracle(num_envs, D, config=cfg, nthreads=8)
@@ -512,3 +512,24 @@ def test_parity_with_silent_senders(explicit):
             assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all(), k
         assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
     assert (env.get_state("qlen")[:, 1] == 0).all() and (env.get_state("qlen")[:, 3] == 0).all()
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+@pytest.mark.parametrize("t0", [1000.0, 123456.789, 1.05e6, 1.5e6, 3.0e6])
+def test_parity_at_large_simulated_times(t0, explicit):
+    """Runs that START at a large simulated time (test hook `start_time`): coarser f64 binades for every time
+    computation, and past the validity limits of the fast paths one after the other -- decode-certainty classes
+    (t < 1e6), FMA slot remainder (t < 2^40 slots = 1.0995e6 s), tick jump (t < 2^21 s) -- so that the plain
+    fmod, the exact decode sums and the tick loop run on the device.  A run from zero gets there after ~10^8 steps."""
+    import torch
+    N, K, D = 1024, 64, 4
+    env, orc = _mk(N, D, explicit=explicit, start_time=t0)
+    assert (env.get_state("now") == t0).all()
+    dev, dur = action_stream(int(t0) % 97, K, N, D)
+    _run(env, orc, dev, dur, reset_every=20)
+    if not explicit:
+        fo, fr, fd = env.rollout(torch.from_numpy(dev[:32]).cuda(), torch.from_numpy(dur[:32]).cuda())
+        for k in range(32):
+            oo, orr, od = orc.step(dev[k], dur[k])
+            assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all(), k
+        assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")

@@ -455,11 +455,12 @@ def test_chunked_feedback_gather_over_rccl_single_rank():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("switch", ["GW_NO_FASTMATH", "GW_NO_CLASSES", "GW_NO_TICKJUMP"])
+@pytest.mark.parametrize("switch", ["GW_NO_FASTMATH", "GW_NO_CLASSES", "GW_NO_TICKJUMP", "GW_NO_IDEM"])
 def test_parity_with_exact_fast_paths_switched_off(switch, monkeypatch):
     """The fast forms (FMA remainder, 3-op division, integer decode rule, certainty classes, tick jump) are exact
     replacements validated at gw_create; with any of them switched off (read at gw_create) the plain forms run and
-    the results must be the same bits.  Step kernel and fused rollout."""
+    the results must be the same bits.  GW_NO_IDEM makes the kernels count every hearing of a talker through the full
+    transition tables in HBM instead of using the combined LDS tables.  Step kernel and fused rollout."""
     import torch
     monkeypatch.setenv(switch, "1")
     N, K, D = 2048, 72, 4

@@ -550,3 +550,20 @@ def test_parity_with_other_workgroup_sizes(block, monkeypatch):
         env, orc = _mk(N, D)
         dev, dur = action_stream(81, K, N, D)
         _run(env, orc, dev, dur, reset_every=16)
+
+
+@pytest.mark.parametrize("cap", ["0", "16", "48"])
+def test_rollout_chunking_and_fallback(cap, monkeypatch):
+    """GW_ROLLOUT_CAP (read at gw_create): steps per fused launch; 0 switches the fused kernel off, so gw_rollout
+    falls back to one step launch per step.  Same results either way."""
+    import torch
+    monkeypatch.setenv("GW_ROLLOUT_CAP", cap)
+    N, K, D = 1024, 70, 4
+    env, orc = _mk(N, D)
+    dev, dur = action_stream(91, K, N, D)
+    assert (env.reset().cpu().numpy() == orc.reset()).all()
+    fo, fr, fd = env.rollout(torch.from_numpy(dev).cuda(), torch.from_numpy(dur).cuda())
+    for k in range(K):
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all() and (fd[k].cpu().numpy() == od).all(), k
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")

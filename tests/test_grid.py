@@ -22,7 +22,7 @@ def test_grid_oracle_scenario_is_deterministic_and_collides():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,N,T", [(2, 6, 0.25), (4, 6, 0.2), (9, 5, 0.15), (16, 4, 0.12), (20, 2, 0.08)])
+@pytest.mark.parametrize("n,N,T", [(2, 6, 0.25), (4, 6, 0.2), (9, 5, 0.15), (16, 4, 0.12), (20, 2, 0.08), (33, 2, 0.05), (64, 2, 0.04)])
 def test_grid_kernel_matches_event_driven_oracle(n, N, T):
     import gymwipe_amd
     from oracle import des_model as dm
@@ -58,7 +58,7 @@ def test_grid_rng_is_shared_with_the_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,N,T", [(2, 4, 0.2), (4, 4, 0.15), (9, 3, 0.1), (16, 2, 0.07)])
+@pytest.mark.parametrize("n,N,T", [(2, 4, 0.2), (4, 4, 0.15), (9, 3, 0.1), (16, 2, 0.07), (40, 1, 0.03)])
 def test_mobile_grid_kernel_matches_event_driven_oracle(n, N, T):
     """mobile_device_grid (tests/test_benchmark.py:73-85): positions change every 1 ms, so attenuation,
     received power and BER move WHILE packets are being received (simple_stack.py:119-128,223-231)."""

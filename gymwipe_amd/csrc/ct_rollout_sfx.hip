@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
 
     const StepMath m(c);
     const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
-    const double inv_interval = c.inv_interval;
+    const double inv_interval = c.inv_interval, tie_filter = c.tie_filter;
     const bool fast_ticks = c.fast_ticks != 0;
     const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
     const int mh = c.mac_hdr, pv = c.payload_value;
@@ -278,6 +278,21 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
 
         // (2) close the step (A.5 + interpreter feedback); the other senders' queues stay lazy
         if (finish) {
+            // A.5, lazily: the counter ticks between the end of the window and the end of the step are counted by the
+            // next step's first count (counting is cumulative in time).  What must not be lost is the diagnostic bit
+            // for a tick falling EXACTLY on t_end.  A tie needs (t_end - wake) / interval within tie_filter of an
+            // integer (host-side bound on the accumulated rounding of the running sum, gw_api.cpp); only then is the
+            // exact comparison made, by the plain loop.
+            {
+                const double dd = t_end - wake;
+                if (dd >= 0.0) {
+                    const double q = dd * inv_interval;
+                    if (!(fabs(q - rint(q)) > tie_filter) || !(wake >= 0.0625) || !(wake < 2097152.0)) {
+                        for (double w = wake; w <= t_end; w = w + interval)
+                            if (w == t_end) fl |= GW_FLAG_TIE;
+                    }
+                }
+            }
             // the listeners' noise states: nothing to look up once every one of them is terminal
             bool all_term = true;
 #pragma unroll

@@ -139,6 +139,15 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
     k.cls_limit = (no_fast || getenv("GW_NO_CLASSES")) ? 0.0 : 1.0e6;
     k.fast_decide = (!no_fast && cfg->max_ber == 0.25 && tab.coded_factor * 8.0 == floor(tab.coded_factor * 8.0)) ? 1 : 0;
     k.inv_interval = 1.0 / cfg->counter_interval;
+    {
+        // If tick number j after `wake` equals t exactly, then t - wake = j*c + E with |E| <= j * ulp(t)/2 (one rounding per
+        // addition of the running sum), so (t - wake)/c is within j*ulp(t)/(2c) of j.  j <= jmax ticks per step, t < 2^21 s
+        // where the filter is used; x8 for the roundings of the estimate itself and margin.
+        const double step_max = (double)cfg->max_duration * cfg->duration_factor * cfg->slot + 0.05;
+        const double jmax = ceil(step_max / cfg->counter_interval) + 2.0;
+        k.tie_filter = 8.0 * jmax * ldexp(1.0, 21 - 52) / (2.0 * cfg->counter_interval);
+        if (!(k.tie_filter < 0.25)) k.tie_filter = 1.0;     // filter useless: always compare exactly
+    }
     k.fast_ticks = (!no_fast && !getenv("GW_NO_TICKJUMP") && gw_fast_ticks_ok(cfg->counter_interval)) ? 1 : 0;
     k.idem_states = 1;                              // hearing the same talker twice changes nothing more
     for (int to = 0; to < R && k.idem_states; ++to)

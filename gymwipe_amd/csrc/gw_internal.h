@@ -29,6 +29,7 @@ struct GwDevConst {
     double  start_time;                 // simulated time at creation (test hook; the reference starts at 0)
     int32_t fast_ticks;                 // gw_tick_jump validated for counter_interval
     double  inv_interval;               // RN(1/counter_interval)
+    double  tie_filter;                 // a tick can only fall exactly on t when (t - wake)/interval is this close to an integer
     int32_t no_traffic, peer_receive, float_duration;   // GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION
     int32_t dest[GW_MAX_DEVICES];
 };

@@ -32,6 +32,7 @@ What is restated, and from where (file:line relative to the reference tree):
   * gymwipe/networking/simple_stack.py:32-286 (SimplePhy), :289-484
     (SimpleMac), :486-561 (SimpleRrmMac)
   * gymwipe/networking/devices.py:40-111,113-203 (network / RRM devices)
+  * gymwipe/networking/construction.py:77-174 (gates, ports), :221-342 (gate listeners)
   * gymwipe/envs/core.py:14-57,142-153 and gymwipe/envs/counter_traffic.py
     (the benchmarked environment, including its quirks: swapped payload
     constructor arguments :57, reset() that does not rewind time :135-144)
@@ -43,7 +44,12 @@ scenario in `scenario_*` below and asserted in tests/test_oracle_pinning.py:
     tests/envs/test_counter_traffic.py:25-34   (+2/-2.0 then 0/+2.0)
     tests/networking/test_stack.py:219-235     (4, 4, 8, 8, 10/10 deliveries)
     tests/networking/test_stack.py:102-124,128 (PHY transmission properties)
-    tests/test_simtools.py:60-120              (process admission counts)
+    tests/test_simtools.py:16-43,60-120        (callback priorities, process admission counts)
+    tests/networking/test_construction.py:18-40,73-135,137-200
+                                               (ports; module ping-pong 19/20 at t=20, ten receptions per port at
+                                                t=40; gate-listener admission)
+    tests/networking/test_messages.py:6-14     (packet sizes)
+-- i.e. every test of the reference that pins a result on this path.
 Everything those tests do not cover (long rollouts, D=4/16 compositions) is
 "parity unpinned" against the live reference and is only cross-checked
 between this restatement and the independently written C restatement

@@ -45,30 +45,30 @@ GW_HD double gw_fast_div(double a, double b, double rcp)
 GW_HD bool gw_tick_jump(double wake, double t, double c, double inv_c, bool inclusive,
                         uint32_t* n, double* wake_out, bool* tie)
 {
-    *tie = false;
-    if (inclusive ? !(wake <= t) : !(wake < t)) { *n = 0u; *wake_out = wake; return true; }
-    if (!(wake >= 0.0625) || !(wake < 2097152.0)) return false;
+    // straight-line on purpose: on the GPU a chain of early returns becomes a nest of exec-mask regions that costs
+    // more than the arithmetic it skips; every quantity below is harmless to compute when a precondition fails
+    const bool any = inclusive ? (wake <= t) : (wake < t);
     const double w1 = wake + c, w2 = w1 + c;
     const double delta = w1 - wake;
-    if (!((w2 - w1) == delta)) return false;
     union { double f; uint64_t u; } hi;                   // 2^(exponent(wake) + 1): the end of wake's binade
     hi.f = wake;
     hi.u = (hi.u & 0x7ff0000000000000ull) + 0x0010000000000000ull;
-    const double d = t - wake;                            // exact: wake <= t < 2*wake
-    if (!(d < 0.0625)) return false;
+    const double d = t - wake;                            // exact when wake <= t < 2*wake
     double n0 = floor(d * inv_c);
     double r = fma(-n0, delta, d);                        // exact
-    if (r < 0.0) { n0 -= 1.0; r += delta; }
-    else if (r >= delta) { n0 += 1.0; r -= delta; }
-    if (!(r >= 0.0 && r < delta) || !(n0 >= 0.0)) return false;
+    const bool low = r < 0.0, high = r >= delta;          // the estimate is off by at most one
+    n0 = low ? n0 - 1.0 : (high ? n0 + 1.0 : n0);
+    r = low ? r + delta : (high ? r - delta : r);
     const bool hit = r == 0.0;                            // tick number n0 falls exactly on t
     const double cnt = (inclusive || !hit) ? n0 + 1.0 : n0;
     const double nw = fma(cnt, delta, wake);
-    if (!(nw < hi.f)) return false;                       // the next tick would leave the binade
-    *n = (uint32_t)cnt;
-    *wake_out = nw;
-    *tie = inclusive && hit;
-    return true;
+    const bool ok = (wake >= 0.0625) && (wake < 2097152.0) && ((w2 - w1) == delta) && (d < 0.0625) &&
+                    (r >= 0.0) && (r < delta) && (n0 >= 0.0) && (nw < hi.f);   // last: the next tick stays in the binade
+    const bool use = any && ok;
+    *n = use ? (uint32_t)cnt : 0u;
+    *wake_out = use ? nw : wake;
+    *tie = use && inclusive && hit;
+    return ok || !any;
 }
 
 // ---- host-side validation (plain host functions) ----

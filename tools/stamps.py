@@ -28,10 +28,15 @@ for k in range(48):
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         w = out[: N // 64].astype(np.int64)
         rows.append(np.diff(w[:, :13], axis=1))
-        t0 = w[:, 0].min()
-        starts = w[:, 0] - t0
-        ends = w[:, 12] - t0
-        skew.append((np.median(starts), np.percentile(starts, 99), starts.max(), np.median(ends), ends.max()))
+        # s_memtime counters are per XCD (workgroup i runs on XCD i % 8): offsets only make sense within one
+        st, en = [], []
+        for x in range(8):
+            wx = w[x::8]
+            t0 = wx[:, 0].min()
+            st.append(wx[:, 0] - t0)
+            en.append(wx[:, 12] - t0)
+        st, en = np.concatenate(st), np.concatenate(en)
+        skew.append((np.median(st), np.percentile(st, 99), st.max(), np.median(en), en.max()))
 d = np.concatenate(rows)
 print("cycles per wave (s_memtime ticks), median / p90 / mean over %d waves x %d launches" % (N // 64, len(rows)))
 for i, n in enumerate(names):
@@ -39,5 +44,5 @@ for i, n in enumerate(names):
 tot = d.sum(axis=1)
 print("  %-48s %8.0f %8.0f %8.0f" % ("total in-kernel", np.median(tot), np.percentile(tot, 90), tot.mean()))
 sk = np.array(skew)
-print("wave start / end relative to the launch's first wave (ticks; median over launches of: median start, p99 start, "
+print("wave start / end relative to the first wave of the same XCD (ticks; median over launches of: median start, p99 start, "
       "last start, median end, last end): %.0f %.0f %.0f %.0f %.0f" % tuple(np.median(sk, axis=0)))

@@ -349,12 +349,11 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                     }
                     const bool ok = decode(m, cls_x, cls_valid, ber_x, x, br, hdr_bits,
                                            (double)(pay * 8) * coded_factor, fl);
-                    if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
-                        k.deliv++;
-                        rvm |= (1u << d);
-                        if (pv == cbound) dn = 1u;
-                    }
-                    if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
+                    // devices.py:163-168, counter_traffic.py:75-80 (as selects)
+                    k.deliv += ok ? 1u : 0u;
+                    rvm |= ok ? (1u << d) : 0u;
+                    dn = (ok && pv == cbound) ? 1u : dn;
+                    fl |= !(x.t_e < t_end) ? (uint32_t)GW_FLAG_CARRY : 0u;
                     ticks_to(x.t_e, true);                                // ticks are older events than the MAC's resume
                     cur = x.t_e;
                     if (!(cur < stopw)) break;                            // window timeout already processed

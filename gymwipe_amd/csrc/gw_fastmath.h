@@ -14,10 +14,9 @@
 GW_HD double gw_fast_fmod(double t, double slot, double inv_slot)
 {
     const double q = floor(t * inv_slot);
-    double r = fma(-q, slot, t);
-    if (r < 0.0) r += slot;
-    else if (r >= slot) r -= slot;
-    return r;
+    const double r = fma(-q, slot, t);
+    const double up = r + slot, down = r - slot;          // selects, not branches: cheaper than exec-mask regions on the GPU
+    return (r < 0.0) ? up : ((r >= slot) ? down : r);
 }
 
 // a / b for the integer-valued numerators the step produces (bit counts), b = data rate:

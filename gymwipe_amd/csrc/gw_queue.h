@@ -42,13 +42,13 @@ GW_HD uint32_t gw_ceil_div(uint32_t len, uint32_t mult, uint32_t inv16)
 // breakpoints (entries nbp-1 and nbp-2 of the history ring); older ones are read from `hist`.
 GW_HD uint32_t gw_tick_value(uint32_t t, GwBp cur, GwBp prev, uint32_t nbp, const GwBp* hist, uint32_t bound)
 {
-    GwBp b = cur;
-    if (t < cur.t0) {
-        b = prev;
-        if (t < prev.t0) {                       // more than two resets inside the queue's span: rare
-            uint32_t j = nbp - 2u;
-            do { --j; b = hist[j & GW_RING_MASK]; } while (t < b.t0);
-        }
+    const bool older = t < cur.t0;               // (a select, not a branch: the common cases stay straight-line)
+    GwBp b;
+    b.t0 = older ? prev.t0 : cur.t0;
+    b.c0 = older ? prev.c0 : cur.c0;
+    if (older && t < prev.t0) {                  // more than two resets inside the queue's span: rare
+        uint32_t j = nbp - 2u;
+        do { --j; b = hist[j & GW_RING_MASK]; } while (t < b.t0);
     }
     return gw_min_u32(b.c0 + (t - b.t0), bound);
 }

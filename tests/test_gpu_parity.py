@@ -567,3 +567,38 @@ def test_rollout_chunking_and_fallback(cap, monkeypatch):
         oo, orr, od = orc.step(dev[k], dur[k])
         assert (fo[k].cpu().numpy() == oo).all() and (fr[k].cpu().numpy() == orr).all() and (fd[k].cpu().numpy() == od).all(), k
     assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
+
+
+def test_two_handles_driven_from_two_host_threads():
+    """a handle is not thread-safe, but different handles may be driven from different host threads
+    (ctypes releases the GIL during the calls; errors are thread-local).  Each thread uses its own stream."""
+    import threading
+    import torch
+    N, D, K = 2048, 4, 120
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            env, orc = _mk(N, D)
+            dev, dur = action_stream(200 + tid, K, N, D)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                env.reset()
+                orc.reset()
+                for k in range(K):
+                    o, r, d, _ = env.step({"device": torch.from_numpy(dev[k]).cuda(), "duration": torch.from_numpy(dur[k]).cuda()})
+                    oo, orr, od = orc.step(dev[k], dur[k])
+                    s.synchronize()
+                    assert (o.cpu().numpy() == oo).all() and (r.cpu().numpy() == orr).all(), (tid, k)
+                assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="thread %d" % tid)
+            results[tid] = True
+        except Exception as exc:                              # surfaced in the main thread below
+            errors.append((tid, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert results == {0: True, 1: True}

@@ -31,6 +31,7 @@ EXPORTS = (
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
     "gw_plant_state_ptr", "gw_plant_get_state", "gw_plant_feedback", "gw_plant_update_feedback", "gw_now_ptr",
+    "gw_ctrl_config_default", "gw_ctrl_create", "gw_ctrl_destroy", "gw_ctrl_step", "gw_ctrl_get_state",
     "gw_grid_config_default", "gw_grid_create", "gw_grid_destroy", "gw_grid_run", "gw_grid_get_state", "gw_grid_set_position",
 )
 
@@ -62,6 +63,14 @@ class Config(C.Structure):
         ("max_duration", C.c_int32),
         ("extra_att_db", (C.c_double * MAX_RADIOS) * MAX_RADIOS),
         ("start_time", C.c_double),
+    ]
+
+
+class CtrlConfig(C.Structure):
+    _fields_ = [
+        ("net", Config),
+        ("A", C.c_double * 16), ("B", C.c_double * 4), ("x0", C.c_double * 4), ("u0", C.c_double),
+        ("ctrl_start_tick", C.c_int32), ("ctrl_period_ticks", C.c_int32),
     ]
 
 
@@ -176,6 +185,11 @@ def lib():
     L.gw_plant_state_ptr.argtypes, L.gw_plant_state_ptr.restype = [vp, C.POINTER(vp)], C.c_int
     L.gw_plant_get_state.argtypes, L.gw_plant_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     L.gw_plant_feedback.argtypes, L.gw_plant_feedback.restype = [vp, vp, vp, vp, vp], C.c_int
+    L.gw_ctrl_config_default.argtypes, L.gw_ctrl_config_default.restype = [C.POINTER(CtrlConfig), i64], C.c_int
+    L.gw_ctrl_create.argtypes, L.gw_ctrl_create.restype = [C.POINTER(CtrlConfig), C.POINTER(vp)], C.c_int
+    L.gw_ctrl_destroy.argtypes, L.gw_ctrl_destroy.restype = [vp], C.c_int
+    L.gw_ctrl_step.argtypes, L.gw_ctrl_step.restype = [vp, vp, vp, vp, vp, vp, vp], C.c_int
+    L.gw_ctrl_get_state.argtypes, L.gw_ctrl_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     L.gw_plant_update_feedback.argtypes, L.gw_plant_update_feedback.restype = [vp, vp, C.c_int64, vp, vp, vp, vp], C.c_int
     L.gw_now_ptr.argtypes, L.gw_now_ptr.restype = [vp, C.POINTER(vp), C.POINTER(i64)], C.c_int
     L.gw_grid_config_default.argtypes, L.gw_grid_config_default.restype = [C.POINTER(GridConfig), i64, i32], C.c_int

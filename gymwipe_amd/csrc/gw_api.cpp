@@ -183,6 +183,44 @@ void expand_sfx(uint32_t bound, uint32_t base, uint32_t mult, uint32_t len, uint
 
 } // namespace
 
+// every wave-uniform constant the step kernels need (shared with gw_ctrl_api.cpp)
+int gw_fill_dev_const(const gw_config& cfg, const GwHostTables& tab, GwDevConst& k)
+{
+    const int D = cfg.num_devices, R = D + 1;
+    k.D = D; k.R = R; k.S = GW_MAX_NSTATES;
+    k.counter_bound = cfg.counter_bound; k.payload_value = cfg.payload_value;
+    k.mac_hdr = cfg.mac_header_bytes; k.net_hdr = cfg.net_header_bytes;
+    k.duration_factor = cfg.duration_factor; k.max_duration = cfg.max_duration;
+    for (int i = 0; i < D; ++i) { k.mult[i] = cfg.mult[i]; k.inv16[i] = cfg.mult[i] > 0 ? (65536u + (uint32_t)cfg.mult[i] - 1u) / (uint32_t)cfg.mult[i] : 0u; }
+    k.start_time = cfg.start_time;
+    k.no_traffic = (cfg.flags & GW_CFG_NO_COUNTER_TRAFFIC) ? 1 : 0;
+    k.peer_receive = (cfg.flags & GW_CFG_PEER_RECEIVE) ? 1 : 0;
+    k.float_duration = (cfg.flags & GW_CFG_FLOAT_DURATION) ? 1 : 0;
+    for (int i = 0; i < D; ++i) k.dest[i] = cfg.dest[i];
+    k.slot = cfg.slot; k.data_rate = tab.data_rate; k.bit_rate = cfg.bit_rate;
+    k.coded_factor = tab.coded_factor; k.max_ber = cfg.max_ber; k.counter_interval = cfg.counter_interval;
+    {
+        volatile double hb = (double)(cfg.mac_header_bytes * 8);
+        k.hdr_dur = hb / tab.data_rate;        // physical.py:244
+        k.hdr_bits = hb * tab.coded_factor;    // physical.py:259
+    }
+
+    set_fast_paths(cfg, tab, k);
+    for (int j = 0; j < R; ++j) {
+        uint16_t m = 0;
+        for (int s0 = 0; s0 < tab.nstates[j]; ++s0) {
+            bool fixed = true;
+            for (int f = 0; f < R && fixed; ++f)
+                if (f != j && tab.trans[((size_t)j * R + f) * GW_MAX_NSTATES + s0] != s0) fixed = false;
+            if (fixed) m |= (uint16_t)(1u << s0);
+        }
+        k.term[j] = m;
+    }
+    return GW_OK;
+}
+
+int gw_validate_config(const gw_config& cfg) { return validate(cfg); }
+
 extern "C" {
 
 int gw_abi_version(void) { return GW_ABI_VERSION; }
@@ -268,35 +306,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     const int D = cfg->num_devices, R = D + 1;
     const int64_t N = cfg->num_envs;
     GwDevConst& k = env->cst_host;
-    k.D = D; k.R = R; k.S = GW_MAX_NSTATES;
-    k.counter_bound = cfg->counter_bound; k.payload_value = cfg->payload_value;
-    k.mac_hdr = cfg->mac_header_bytes; k.net_hdr = cfg->net_header_bytes;
-    k.duration_factor = cfg->duration_factor; k.max_duration = cfg->max_duration;
-    for (int i = 0; i < D; ++i) { k.mult[i] = cfg->mult[i]; k.inv16[i] = cfg->mult[i] > 0 ? (65536u + (uint32_t)cfg->mult[i] - 1u) / (uint32_t)cfg->mult[i] : 0u; }
-    k.start_time = cfg->start_time;
-    k.no_traffic = (cfg->flags & GW_CFG_NO_COUNTER_TRAFFIC) ? 1 : 0;
-    k.peer_receive = (cfg->flags & GW_CFG_PEER_RECEIVE) ? 1 : 0;
-    k.float_duration = (cfg->flags & GW_CFG_FLOAT_DURATION) ? 1 : 0;
-    for (int i = 0; i < D; ++i) k.dest[i] = cfg->dest[i];
-    k.slot = cfg->slot; k.data_rate = env->tab.data_rate; k.bit_rate = cfg->bit_rate;
-    k.coded_factor = env->tab.coded_factor; k.max_ber = cfg->max_ber; k.counter_interval = cfg->counter_interval;
-    {
-        volatile double hb = (double)(cfg->mac_header_bytes * 8);
-        k.hdr_dur = hb / env->tab.data_rate;        // physical.py:244
-        k.hdr_bits = hb * env->tab.coded_factor;    // physical.py:259
-    }
-
-    set_fast_paths(*cfg, env->tab, k);
-    for (int j = 0; j < R; ++j) {
-        uint16_t m = 0;
-        for (int s0 = 0; s0 < env->tab.nstates[j]; ++s0) {
-            bool fixed = true;
-            for (int f = 0; f < R && fixed; ++f)
-                if (f != j && env->tab.trans[((size_t)j * R + f) * GW_MAX_NSTATES + s0] != s0) fixed = false;
-            if (fixed) m |= (uint16_t)(1u << s0);
-        }
-        k.term[j] = m;
-    }
+    gw_fill_dev_const(*cfg, env->tab, k);
 
     GwState& st = env->st;
     st.N = N; st.D = D; st.R = R;

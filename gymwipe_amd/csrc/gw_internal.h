@@ -138,6 +138,28 @@ int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream);
 int gw_grid_launch_set_position(const GwGridDev& g, int dev, const double* xs, const double* ys, void* stream);
 int gw_grid_launch_init(const GwGridDev& g, const double* delays_dev, const double* pos_dev, double thermal, void* stream);
 
+struct GwHostTables;
+
+// Closed control loop (ctrl_step.hip, gw_ctrl_api.cpp)
+struct GwCtrlDev {
+    int64_t N;
+    double *now, *wake, *x, *u, *ang;          // [N], [N], [N][4], [N], [N]
+    uint32_t *ktick, *got, *ntx, *ncmd, *nsub, *flags;   // [N], [N][2], [N] ...
+    uint16_t* qhl;                             // [2][N]  head | len << 8 of the sensor's and the controller's queue
+    uint8_t*  rxs;                             // [4][N]  rx-power state per radio
+    double*   pay;                             // [N][2][GW_RING_PHYS] payload values of the queued packets
+    double A[16], B[4];
+    uint32_t start, period;
+    const GwDevConst* cst;
+    const uint8_t* trans;                      // [4][4][S]
+    const double*  ber;                        // [4][4][S]
+};
+int gw_ctrl_launch_step(const GwCtrlDev& c, const int32_t* device, const int32_t* duration, int32_t* obs, float* reward,
+                        double* angle_deg, void* stream);
+int gw_ctrl_launch_init(const GwCtrlDev& c, const double* x0, double u0, void* stream);
+int gw_fill_dev_const(const gw_config& cfg, const GwHostTables& tab, GwDevConst& k);   // gw_api.cpp
+int gw_validate_config(const gw_config& cfg);                                           // gw_api.cpp
+
 // Host-side link tables (gw_tables.cpp)
 struct GwHostTables {
     int D, R;

@@ -5,7 +5,7 @@ Environment registry with the reference's ids (gymwipe/envs/__init__.py:6-14).
 """
 from .core import BaseEnv, Interpreter, VecInterpreter, VecPayload       # noqa: F401
 from .counter_traffic import CounterTrafficEnv, VecCounterTrafficEnv     # noqa: F401
-from .inverted_pendulum import InvertedPendulumEnv, VecInvertedPendulumEnv   # noqa: F401
+from .inverted_pendulum import InvertedPendulumEnv, VecControlLoopEnv, VecInvertedPendulumEnv   # noqa: F401
 
 registry = {}
 
@@ -29,6 +29,7 @@ register(id='VecCounterTraffic-v0', entry_point=VecCounterTrafficEnv)
 # here it is the env as shipped (open loop) over a builder-defined linear plant: see inverted_pendulum.py
 register(id='InvertedPendulum-v0', entry_point=InvertedPendulumEnv)
 register(id='VecInvertedPendulum-v0', entry_point=VecInvertedPendulumEnv)
+register(id='VecControlLoop-v0', entry_point=VecControlLoopEnv)
 
 try:  # pragma: no cover - gym is not installed in the build image
     from gym.envs.registration import register as _gym_register

@@ -108,3 +108,78 @@ class InvertedPendulumEnv(VecInvertedPendulumEnv):
         self._act[0, 0] = int(action["device"])
         self._act[1, 0] = int(action["duration"])
         return self._scalars(VecInvertedPendulumEnv.step(self, {"device": self._act[0], "duration": self._act[1]}))
+
+
+class VecControlLoopEnv(BaseEnv):
+    """The pendulum env with its control loop CLOSED over receive-mode MACs: what the reference
+    intends (sensor -> controller -> actuator, plants/sliding_pendulum.py:116-155, control/inverted_pendulum.py:16-69)
+    but never runs.  Builder-defined where the reference leaves it open -- see ``gw_ctrl_config`` in
+    include/gymwipe_amd.h for the rules -- and checked bit for bit against an event-driven model of those rules.
+    Same gym surface as ``VecInvertedPendulumEnv``: ``step({"device": int32[N] in {0 sensor, 1 controller},
+    "duration": int32[N]}) -> (obs, reward, done, {"Sensor angle": deg})``."""
+    SENSOR, CONTROLLER, ACTUATOR = 0, 1, 2
+
+    def __init__(self, num_envs, device="cuda:0", ctrl_start_tick=None, ctrl_period_ticks=None, positions=None, x0=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self._torch = torch
+        self._L = nat.lib()
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        BaseEnv.__init__(self, 2)
+        self.observation_space = spaces.Discrete(180)
+        cfg = nat.CtrlConfig()
+        nat.check(self._L.gw_ctrl_config_default(C.byref(cfg), self.num_envs))
+        cfg.net.hip_device = self.device.index or 0
+        if ctrl_start_tick is not None:
+            cfg.ctrl_start_tick = int(ctrl_start_tick)
+        if ctrl_period_ticks is not None:
+            cfg.ctrl_period_ticks = int(ctrl_period_ticks)
+        if positions is not None:                          # sensor, controller, actuator, RRM
+            for i, (x, y) in enumerate(positions):
+                cfg.net.pos[i][0], cfg.net.pos[i][1] = float(x), float(y)
+        if x0 is not None:
+            for i, v in enumerate(x0):
+                cfg.x0[i] = float(v)
+        self.config = cfg
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_ctrl_create(C.byref(cfg), C.byref(self._h)))
+            n = self.num_envs
+            self._obs = torch.empty(n, dtype=torch.int32, device=self.device)
+            self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._angle = torch.empty(n, dtype=torch.float64, device=self.device)
+            self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+
+    def step(self, action):
+        torch = self._torch
+        dev = action["device"].to(device=self.device, dtype=torch.int32).contiguous()
+        dur = action["duration"].to(device=self.device, dtype=torch.int32).contiguous()
+        assert dev.shape == (self.num_envs,) and dur.shape == (self.num_envs,)
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_ctrl_step(self._h, dev.data_ptr(), dur.data_ptr(), self._obs.data_ptr(), self._rew.data_ptr(),
+                                           self._angle.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+        return self._obs, self._rew, self._done, {"Sensor angle": self._angle}
+
+    _FIELDS = {"now": ((), "f8"), "wake": ((), "f8"), "u": ((), "f8"), "angle_deg": ((), "f8"), "x": ((4,), "f8"),
+               "rx_power": ((4,), "f8"), "qlen": ((2,), "i4"), "received": ((2,), "u4"), "n_tx": ((), "u4"),
+               "commands": ((), "u4"), "substeps": ((), "u4"), "flags": ((), "u4")}
+
+    def get_state(self, field):
+        import numpy as np
+        shape, dt = self._FIELDS[field]
+        out = np.empty((self.num_envs,) + shape, np.dtype(dt))
+        nat.check(self._L.gw_ctrl_get_state(self._h, field.encode(), out.ctypes.data, out.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.gw_ctrl_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -295,6 +295,35 @@ int gw_grid_set_position(gw_grid* g, int32_t device, const double* x_host, const
  *              | "rx_power" f64[N][n] | "pos" f64[N][n][2] */
 int gw_grid_get_state(gw_grid* g, const char* field, void* dst_host, size_t bytes);
 
+/* ---- Control loop (second half): the pendulum env with its loop closed -------------------------------
+ * BUILDER-DEFINED: the reference intends this loop (plants/sliding_pendulum.py:116-155, control/inverted_pendulum.py:16-69,
+ * envs/inverted_pendulum.py:60-113) but never runs it -- nobody sets `receiving`, and the env cannot be constructed.  Three
+ * network devices (sensor 0, controller 1, actuator 2 -- not assignable) and the RRM; the sensor queues the plant angle
+ * every counter tick and the plant then advances one substep x <- A x + B u; every ctrl_period_ticks from ctrl_start_tick on
+ * the controller queues -angle_deg (the shipped PID gains kp = 1, ki = kd = 0) unless its angle is 0; packets decoded by
+ * their destination's receive-mode MAC are handed up (controller: angle := degrees(value); actuator: u := value);
+ * observation and reward as InvertedPendulumInterpreter computes them.  Checked bit for bit against an event-driven
+ * model of the same rules; parity with the reference is unpinned by construction. */
+typedef struct gw_ctrl_config {
+    gw_config net;                          /* num_devices must be 3; geometry, radio constants, counter_interval */
+    double  A[16], B[4];                    /* one-substep plant matrices (row-major), substep = counter_interval */
+    double  x0[4], u0;                      /* initial plant state {wagon pos, wagon vel, angle, angle rate}, initial input */
+    int32_t ctrl_start_tick;                /* first control tick */
+    int32_t ctrl_period_ticks;              /* control period in ticks (10 = the reference's 10 ms) */
+} gw_ctrl_config;
+
+typedef struct gw_ctrl gw_ctrl;
+
+int gw_ctrl_config_default(gw_ctrl_config* cfg, int64_t num_envs);
+int gw_ctrl_create(const gw_ctrl_config* cfg, gw_ctrl** out);
+int gw_ctrl_destroy(gw_ctrl* c);
+/* one env.step() of every env: device in {0 sensor, 1 controller}, duration in [0, max_duration); angle_deg_dev may be NULL */
+int gw_ctrl_step(gw_ctrl* c, const int32_t* device_dev, const int32_t* duration_dev, int32_t* obs_dev, float* reward_dev,
+                 double* angle_deg_dev, void* stream);
+/* host copies: "now","wake","u","angle_deg" f64[N] | "x" f64[N][4] | "rx_power" f64[N][4] | "qlen" int32[N][2] |
+ *              "received" u32[N][2] (controller, actuator) | "n_tx","commands","substeps","flags" u32[N] */
+int gw_ctrl_get_state(gw_ctrl* c, const char* field, void* dst_host, size_t bytes);
+
 /* Host-only self-test hook (no GPU needed): fuzzes the MAC-queue encoding the default kernel uses
  * against an explicit deque(maxlen=100).  Returns the number of mismatches (0 = identical). */
 int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);

@@ -942,6 +942,140 @@ class CounterTrafficModel:
 
 
 # --------------------------------------------------------------------------
+# Networked control loop (second half) -- BUILDER-DEFINED
+# --------------------------------------------------------------------------
+class LinearPlant:
+    """x <- A x + B u per substep, each row evaluated left to right without
+    fused multiply-adds (the order the HIP kernel uses)."""
+
+    def __init__(self, A, B, x0, u0):
+        self.A, self.B = [list(r) for r in A], list(B)
+        self.x, self.u = list(x0), float(u0)
+        self.substeps = 0
+
+    def step(self):
+        x, u, nx = self.x, self.u, []
+        for i in range(4):
+            acc = self.A[i][0] * x[0]
+            acc = acc + self.A[i][1] * x[1]
+            acc = acc + self.A[i][2] * x[2]
+            acc = acc + self.A[i][3] * x[3]
+            acc = acc + self.B[i] * u
+            nx.append(acc)
+        self.x = nx
+        self.substeps += 1
+
+
+def default_plant_matrices(dt=1e-3):
+    """The builder-defined pendulum of gw_plant_config_default (forward Euler)."""
+    tau, g_l, damp = 0.05, 9.81, 0.2
+    Ac = [[0, 1, 0, 0], [0, -1 / tau, 0, 0], [0, 0, 0, 1], [0, 1 / tau, -g_l, -damp]]
+    Bc = [0, 1 / tau, 0, -1 / tau]
+    A = [[(1.0 if i == j else 0.0) + dt * Ac[i][j] for j in range(4)] for i in range(4)]
+    return A, [dt * b for b in Bc]
+
+
+class ControlLoopModel:
+    """The pendulum env with its loop CLOSED, as the reference intends it (envs/inverted_pendulum.py:60-113,
+    plants/sliding_pendulum.py:116-155, control/inverted_pendulum.py:16-69) but never runs it (nobody sets
+    `receiving`).  Builder-defined choices, all stated:
+      * three network devices -- sensor (index 0), controller (1), actuator (2, not assignable) -- and the RRM;
+        controller and actuator have `receiving = True` (networking/devices.py:71-111);
+      * every SAMPLE_INTERVAL the sensor sends the plant's angle (value = angle, 2 bytes: the reference's
+        Transmittable(2, angle) has the arguments swapped) and then advances the plant by one substep
+        (OdePlant.updateState in whole substeps, plants/core.py:38-49); positions stay fixed;
+      * the controller keeps the angle of the last sensor packet it received, in degrees (control/..:39-41), and
+        every `period` ticks from tick `start` on sends -angle as the motor velocity when the angle is not 0
+        (the PID of :52-69 with its shipped gains kp=1, ki=kd=0; aligned to the tick grid instead of its own
+        1 s + k*10 ms timer);
+      * the actuator applies the velocity of every command it receives (sliding_pendulum.py:154-155);
+      * observation / reward as InvertedPendulumInterpreter computes them (envs/inverted_pendulum.py:27-57)."""
+    SENSOR, CONTROLLER, ACTUATOR = 0, 1, 2
+
+    def __init__(self, positions=((0.0, 0.0), (0.0, -1.0), (0.5, 0.0)), rrm_pos=(0.0, 1.0), start=20, period=10,
+                 A=None, B=None, x0=(0.0, 0.0, 0.05, 0.0), u0=0.1):
+        if A is None:                        # input sign chosen so that the reference's control law (u = -angle) damps
+            A, B = default_plant_matrices()
+            B = [-b for b in B]
+        self.world = World()
+        self.sim = sim = self.world.sim
+        self.plant = LinearPlant(A, B, x0, u0)
+        self.devs = [NetDevice(self.world, n, x, y) for n, (x, y) in zip(("Sensor", "Controller", "Actuator"), positions)]
+        sensor, controller, actuator = self.devs
+        self.angle_deg = 0.0                 # the controller's view
+        self.start, self.period = start, period
+        self.tick = 0
+        self.n_cmd = 0
+
+        def sensor_proc():
+            while True:
+                sensor.send(Blob(self.plant.x[2], 2), controller.mac_addr)
+                self.plant.step()
+                yield sim.timeout(COUNTER_INTERVAL)
+
+        def controller_proc():
+            k = 0
+            while True:
+                if k >= self.start and (k - self.start) % self.period == 0 and self.angle_deg != 0.0:
+                    controller.send(Blob(-self.angle_deg, 1), actuator.mac_addr)
+                    self.n_cmd += 1
+                k += 1
+                self.tick = k
+                yield sim.timeout(COUNTER_INTERVAL)
+
+        def receiver(dev, on_receive):
+            def loop():
+                while True:
+                    cmd = Cmd(sim, "RECEIVE", duration=100)          # RECEIVE_TIMEOUT, devices.py:66
+                    dev.mac.net_in.trigger(cmd)
+                    res = yield cmd.done
+                    if res is not None:
+                        on_receive(res)
+            sim.process(loop())
+
+        sim.process(sensor_proc())
+        sim.process(controller_proc())
+        self.got = [0, 0, 0]
+
+        def at_controller(packet):          # the network packet; control/inverted_pendulum.py:39-41
+            self.angle_deg = math.degrees(packet.payload.value)
+            self.got[1] += 1
+
+        def at_actuator(packet):            # sliding_pendulum.py:154-155
+            self.plant.u = packet.payload.value
+            self.got[2] += 1
+        receiver(controller, at_controller)
+        receiver(actuator, at_actuator)
+        idx2mac = {i: d.mac_addr for i, d in enumerate(self.devs)}
+        self.rrm = RrmDevice(self.world, "RRM", rrm_pos[0], rrm_pos[1], idx2mac, _NullInterp())
+
+    def feedback(self):
+        deg = math.degrees(self.plant.x[2])
+        return int(deg), float(abs(180 - deg)), False, {"Sensor angle": deg}
+
+    def step(self, device, duration):
+        assert 0 <= device < 2 and 0 <= duration < MAX_ASSIGN_DURATION
+        sig = self.rrm.assign(device, duration * ASSIGNMENT_DURATION_FACTOR)
+        self.sim.run(sig.done)
+        return self.feedback()
+
+    def snapshot(self):
+        radios = self.devs + [self.rrm]
+        return {"now": self.sim.now, "x": list(self.plant.x), "u": self.plant.u, "angle_deg": self.angle_deg,
+                "qlen": [len(d.mac.queue) for d in self.devs], "received": list(self.got),
+                "substeps": self.plant.substeps, "n_tx": len(self.world.band.log),
+                "rx_power": [r.phy.rx_power for r in radios], "commands": self.n_cmd}
+
+
+class _NullInterp:
+    def on_packet(self, src, dst, payload):
+        pass
+
+    def on_assignment(self, device_index, duration):
+        pass
+
+
+# --------------------------------------------------------------------------
 # The reference's own result-pinning test scenarios, restated
 # --------------------------------------------------------------------------
 def scenario_counter_traffic():

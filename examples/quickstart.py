@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Five-minute tour (needs an MI355X): the reference's scalar env, the vectorised env, a fused rollout, a custom
-interpreter, the pendulum env and the PHY grid.  `python examples/quickstart.py`"""
+interpreter, the pendulum env (open and closed loop) and the PHY grid.  `python examples/quickstart.py`"""
 import os
 import sys
 
@@ -67,6 +67,15 @@ for _ in range(8):
     pobs, prew, pdone, pinfo = penv.step({"device": torch.zeros(4096, dtype=torch.int32, device="cuda"),
                                           "duration": torch.full((4096,), 19, dtype=torch.int32, device="cuda")})
 print("pendulum:", int(pobs[0]), float(prew[0]), float(pinfo["Sensor angle"][0]))
+
+# 5b. the same env with its control loop closed over receive-mode MACs (sensor -> controller -> actuator)
+loop = gymwipe_amd.make("VecControlLoop-v0", num_envs=4096)
+for k in range(60):                                   # alternate the band between sensor and controller, 5 ms each
+    lobs, lrew, ldone, linfo = loop.step({"device": torch.full((4096,), k % 2, dtype=torch.int32, device="cuda"),
+                                          "duration": torch.full((4096,), 5, dtype=torch.int32, device="cuda")})
+rec = loop.get_state("received")
+print("control loop: angle %.3f deg, %d samples reached the controller, %d commands the actuator, motor velocity %.3f"
+      % (float(linfo["Sensor angle"][0]), int(rec[0, 0]), int(rec[0, 1]), float(loop.get_state("u")[0])))
 
 # 6. the reference's PHY-grid benchmark (tests/test_benchmark.py), 1 024 replicas of a 16-device grid
 import numpy as np

@@ -47,5 +47,5 @@ def test_quickstart_example_runs():
                          timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "scalar env: (65538, -2.0, False" in out.stdout and "(65536, 2.0, False" in out.stdout   # the reference's known answer
-    for word in ("vectorised:", "rollout:", "custom interpreter:", "pendulum:", "grid:"):
+    for word in ("vectorised:", "rollout:", "custom interpreter:", "pendulum:", "control loop:", "grid:"):
         assert word in out.stdout

@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 
     if (live) {
         uint32_t rvm = ip.z;
-        if (rvm == 0xdeadbeefu) k_bad = 2;    // touches ip: the stamp below sits after the state loads have landed
+#ifdef GW_STAMPS
+        asm volatile("" : "+v"(rvm));         // diagnostic build: touch ip so that the stamp below sits after the state loads have landed
+#endif
         // The counter record is loaded with the rest of the state but only used at the very end.  vmcnt counts
         // loads AND stores in order on this ISA, so a first use after the state stores would wait for those
         // stores to be acknowledged (a full HBM write round trip on every wave's critical path): use it now.

@@ -106,6 +106,8 @@ int validate(const gw_config& c)
         return fail(GW_EINVAL, "slot, bit_rate, code_rate and counter_interval must be positive");
     if (c.mac_header_bytes < 1 || c.net_header_bytes < 0 || c.counter_bound < 1 || c.duration_factor < 1 || c.max_duration < 1)
         return fail(GW_EINVAL, "header sizes / bounds out of range");
+    if (c.payload_value < 0 || c.payload_value > (1 << 24) || c.counter_bound > (1 << 24))
+        return fail(GW_EINVAL, "payload_value / counter_bound out of range (at most 2^24: packed with flag bits in the state)");
     if (!(c.flags & GW_CFG_EXPLICIT_QUEUE)) {
         for (int i = 0; i < c.num_devices; ++i)
             if (c.mult[i] > GW_MAX_MULT)

@@ -602,3 +602,31 @@ def test_two_handles_driven_from_two_host_threads():
         t.join()
     assert not errors, errors
     assert results == {0: True, 1: True}
+
+
+def test_create_destroy_does_not_leak_device_memory():
+    """Every handle type frees what it allocated: device memory in use returns to its level after many
+    create / destroy cycles."""
+    import gc
+    import torch
+    from gymwipe_amd import VecControlLoopEnv, VecCounterTrafficEnv, VecLinearPlant, VecPhyGrid
+
+    def cycle():
+        for explicit in (False, True):
+            e = VecCounterTrafficEnv(16384, 4, explicit_queue=explicit, peer_receive=explicit)
+            z = torch.zeros(16384, dtype=torch.int32, device="cuda")
+            e.step({"device": z, "duration": z + 3})
+            e.pack_feedback(e._obs, e._rew, e._done)
+            e.close()
+        p = VecLinearPlant(16384); p.close()
+        g = VecPhyGrid(256, 9, np.zeros((256, 9))); g.runSimulation(0.01); g.close()
+        c = VecControlLoopEnv(8192); c.close()
+
+    cycle()
+    torch.cuda.synchronize(); gc.collect()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize(); gc.collect()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)        # allocator granularity, not a per-cycle leak

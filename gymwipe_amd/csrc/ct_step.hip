@@ -50,10 +50,10 @@ __device__ __forceinline__ void tick_append(Ring& r, uint32_t size, int mult, Ta
     }
 }
 
-// all ticks with wake < t (or <= t when inclusive); wake/ctr advance in place
+// all ticks with wake < t (or <= t when inclusive); wake/ctr advance in place; n_ticks counts them
 __device__ __forceinline__ void ticks_until(Ring& r, double& wake, uint32_t& ctr, double t, bool inclusive,
                                             int mult, uint32_t base_bytes, uint32_t bound, double interval,
-                                            Tally& k, uint32_t& flags)
+                                            Tally& k, uint32_t& flags, uint32_t& n_ticks)
 {
     for (;;) {
         const double w = wake;
@@ -62,6 +62,7 @@ __device__ __forceinline__ void ticks_until(Ring& r, double& wake, uint32_t& ctr
             tick_append(r, base_bytes + ctr, mult, k);
             if (ctr < bound) ctr++;
             wake = w + interval;                          // running sum, not k*dt
+            n_ticks++;
         } else break;
     }
 }
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             rd.len = hl_d >> 8;
             const int mult_d = c.mult[d];
             int n_data = 0;
+            uint32_t n_ticks = 0;                                         // counter ticks inside this step
             uint8_t s_r = 0;
             bool s_r_loaded = false;
             uint8_t s_r_old = 0;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 const double stopw = t_r + total;                        // :401 (== timeout time :406)
                 double cur = t_r;
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
-                ticks_until(rd, wake_d, ctr_d, cur, false, mult_d, base_bytes, bound, interval, k, fl);
+                ticks_until(rd, wake_d, ctr_d, cur, false, mult_d, base_bytes, bound, interval, k, fl, n_ticks);
                 for (;;) {
                     if (rd.len == 0) {                                    // :409-416
                         const double w = wake_d;
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                             tick_append(rd, base_bytes + ctr_d, mult_d, k);
                             if (ctr_d < bound) ctr_d++;
                             wake_d = w + interval;
+                            n_ticks++;
                         } else break;
                     }
                     const uint32_t s = rd.base[rd.head];
@@ -194,14 +197,14 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
                     // ticks are older events than the MAC's resume at t_e: they go first
-                    ticks_until(rd, wake_d, ctr_d, x.t_e, true, mult_d, base_bytes, bound, interval, k, fl);
+                    ticks_until(rd, wake_d, ctr_d, x.t_e, true, mult_d, base_bytes, bound, interval, k, fl, n_ticks);
                     cur = x.t_e;
                     if (!(cur < stopw)) break;                            // window timeout already processed
                 }
             }
 
             // ---- A.5: remaining ticks up to the end of the step ----------------------------
-            ticks_until(rd, wake_d, ctr_d, t_end, true, mult_d, base_bytes, bound, interval, k, fl);
+            ticks_until(rd, wake_d, ctr_d, t_end, true, mult_d, base_bytes, bound, interval, k, fl, n_ticks);
             st.qhl[(int64_t)d * N + e] = (uint16_t)(rd.head | (rd.len << 8));
             for (int i = 0; i < D; ++i) {
                 if (i == d) continue;
@@ -210,9 +213,14 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 ri.base = st.ring + (((int64_t)e * D + i) << 7);
                 ri.head = hl & 0xff;
                 ri.len = hl >> 8;
-                double w = wake0;
+                // the same n_ticks ticks d's walk just counted (all senders tick together): no second pass over the
+                // f64 tick times, only the appends
                 uint32_t ct = ctr0;
-                ticks_until(ri, w, ct, t_end, true, c.mult[i], base_bytes, bound, interval, k, fl);
+                const int mult_i = c.mult[i];
+                for (uint32_t n = 0; n < n_ticks; ++n) {
+                    tick_append(ri, base_bytes + ct, mult_i, k);
+                    if (ct < bound) ct++;
+                }
                 st.qhl[(int64_t)i * N + e] = (uint16_t)(ri.head | (ri.len << 8));
             }
 

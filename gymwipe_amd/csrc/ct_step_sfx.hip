@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     uint4 qw[NWC];
 #pragma unroll
     for (int w = 0; w < NWC; ++w) qw[w] = ip;
+    uint32_t dyn_len = 0, dyn_sd = 0;                    // bytes of the record indexed by the action's device
     const uint32_t o32 = e << 5;
     double2 tw = make_double2(0.0, 0.0);
     if (live) {
@@ -156,6 +157,10 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         if (PACKED) {
 #pragma unroll
             for (int w = 0; w < NWC; ++w) qw[w] = ld<uint4>(st.qb, oq + 16u * w);
+            if (NWC > 1 && (unsigned)d < (unsigned)DT) {  // dynamic index into a multi-word record: read the bytes directly
+                dyn_len = st.qb[oq + (uint32_t)d];
+                dyn_sd = st.qb[oq + (uint32_t)(DT + d)];
+            }
         }
         sa0 = ld<uint4>(st.sa, o32);
         sa1 = ld<uint4>(st.sa, o32 + 16u);
@@ -227,16 +232,9 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
                 if (NWC == 1) {
                     len_d = byte_of(qw[0], (uint32_t)d);
                     s_d_old = byte_of(qw[0], (uint32_t)(DT + d));
-                } else {                                  // multi-word record: pick the word by selects, then the byte --
-                    uint4 wl = qw[0], ws = qw[0];         // no second, dependent trip to memory for a dynamic index
-#pragma unroll
-                    for (int w = 1; w < NWC; ++w) {
-                        const bool hl = ((uint32_t)d >> 4) == (uint32_t)w, hs = ((uint32_t)(DT + d) >> 4) == (uint32_t)w;
-                        wl.x = hl ? qw[w].x : wl.x; wl.y = hl ? qw[w].y : wl.y; wl.z = hl ? qw[w].z : wl.z; wl.w = hl ? qw[w].w : wl.w;
-                        ws.x = hs ? qw[w].x : ws.x; ws.y = hs ? qw[w].y : ws.y; ws.z = hs ? qw[w].z : ws.z; ws.w = hs ? qw[w].w : ws.w;
-                    }
-                    len_d = byte_of(wl, (uint32_t)d & 15u);
-                    s_d_old = byte_of(ws, (uint32_t)(DT + d) & 15u);
+                } else {
+                    len_d = dyn_len;
+                    s_d_old = dyn_sd;
                 }
                 s_r_old = (word_of(qw[(2 * DT) >> 4], ((2 * DT) >> 2) & 3) >> (((2 * DT) & 3) * 8)) & 0xffu;
             } else {

@@ -23,11 +23,16 @@ namespace {
 constexpr int CR = 4, CRRM = 3;                             // radios (3 network devices + RRM), index of the RRM
 constexpr int S = GW_MAX_NSTATES;
 
-struct Lane {
-    double now, wake, x[4], u, ang;
-    uint32_t ktick, head[2], len[2], got1, got2, ntx, ncmd, nsub, fl;
-    uint8_t rxs[CR];
+struct Lane {                                               // everything indexed by a run-time device id goes through
+    double now, wake, x[4], u, ang;                         // selects below: a dynamically indexed member array would
+    uint32_t ktick, head[2], len[2], got1, got2, ntx, ncmd, nsub, fl;   // send the whole struct to scratch memory
+    uint32_t rxs[CR];
 };
+
+__device__ __forceinline__ uint32_t pick(const uint32_t (&a)[CR], int i)
+{
+    return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
 
 __device__ __forceinline__ void ring_push(double* ring, uint32_t& head, uint32_t& len, double v)
 {
@@ -46,7 +51,9 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
     Lane L;
     L.now = c.now[e]; L.wake = c.wake[e]; L.u = c.u[e]; L.ang = c.ang[e]; L.ktick = c.ktick[e];
     for (int i = 0; i < 4; ++i) L.x[i] = c.x[e * 4 + i];
+#pragma unroll
     for (int q = 0; q < 2; ++q) { const uint32_t hl = c.qhl[q * c.N + e]; L.head[q] = hl & 0xffu; L.len[q] = hl >> 8; }
+#pragma unroll
     for (int j = 0; j < CR; ++j) L.rxs[j] = c.rxs[j * c.N + e];
     L.got1 = c.got[e * 2]; L.got2 = c.got[e * 2 + 1];
     L.ntx = c.ntx[e]; L.ncmd = c.ncmd[e]; L.nsub = c.nsub[e]; L.fl = c.flags[e];
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
         auto all_hear = [&](int from) {
 #pragma unroll
             for (int j = 0; j < CR; ++j)
-                if (j != from) L.rxs[j] = c.trans[((size_t)j * CR + from) * S + L.rxs[j]];
+                if (j != from) L.rxs[j] = c.trans[((size_t)j * CR + from) * S + L.rxs[j]];   // j is a compile-time index here
         };
 
         const double t_a = L.now;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
         const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(Ld * 8)));
         L.ntx++;
         all_hear(CRRM);
-        const bool granted = receive(m, c.ber[((size_t)d * CR + CRRM) * S + L.rxs[d]], an, br, hdr_bits,
+        const bool granted = receive(m, c.ber[((size_t)d * CR + CRRM) * S + pick(L.rxs, d)], an, br, hdr_bits,
                                      (double)(Ld * 8) * k.coded_factor, L.fl);
         const double t_r = an.t_e;
         const double t_end = t_r + (double)(slots + 1) * slot;
@@ -115,22 +122,24 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
             const int dst = d + 1;                                              // sensor -> controller, controller -> actuator
             double* ring = d == 0 ? ring0 : ring1;
             const uint32_t sz = (uint32_t)(k.mac_hdr + k.net_hdr) + (d == 0 ? 2u : 1u);
+            uint32_t hd_q = d == 0 ? L.head[0] : L.head[1];                    // d's queue in scalars for the loop
             for (;;) {
                 bool closed = false;
-                while (L.len[d] == 0u) {                                        // wait for packet-added or the window timeout
+                while ((d == 0 ? L.len[0] : L.len[1]) == 0u) {                  // wait for packet-added or the window timeout
                     if (L.wake < stopw) { cur = L.wake; tick_all(); }
                     else { closed = true; break; }
                 }
                 if (closed) break;
                 const double need = m.over_rate((double)(sz * 8u));
                 if (!((stopw - cur) > need)) break;
-                const double v = ring[L.head[d]];
-                L.head[d] = (L.head[d] + 1u) & GW_RING_MASK;
-                L.len[d]--;
+                hd_q = d == 0 ? L.head[0] : L.head[1];                          // (a tick may have dropped the oldest entry)
+                const double v = ring[hd_q];
+                hd_q = (hd_q + 1u) & GW_RING_MASK;
+                if (d == 0) { L.head[0] = hd_q; L.len[0]--; } else { L.head[1] = hd_q; L.len[1]--; }
                 const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(((int)sz - mh) * 8)));
                 L.ntx++;
                 all_hear(d);
-                const bool ok = receive(m, c.ber[((size_t)dst * CR + d) * S + L.rxs[dst]], x, br, hdr_bits,
+                const bool ok = receive(m, c.ber[((size_t)dst * CR + d) * S + pick(L.rxs, dst)], x, br, hdr_bits,
                                         (double)(((int)sz - mh) * 8) * k.coded_factor, L.fl);
                 if (!(x.t_e < t_end)) L.fl |= GW_FLAG_CARRY;
                 ticks_until(x.t_e, false);                                      // ticks during the transmission
@@ -153,8 +162,10 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
 
     c.now[e] = L.now; c.wake[e] = L.wake; c.u[e] = L.u; c.ang[e] = L.ang; c.ktick[e] = L.ktick;
     for (int i = 0; i < 4; ++i) c.x[e * 4 + i] = L.x[i];
+#pragma unroll
     for (int q = 0; q < 2; ++q) c.qhl[q * c.N + e] = (uint16_t)(L.head[q] | (L.len[q] << 8));
-    for (int j = 0; j < CR; ++j) c.rxs[j * c.N + e] = L.rxs[j];
+#pragma unroll
+    for (int j = 0; j < CR; ++j) c.rxs[j * c.N + e] = (uint8_t)L.rxs[j];
     c.got[e * 2] = L.got1; c.got[e * 2 + 1] = L.got2;
     c.ntx[e] = L.ntx; c.ncmd[e] = L.ncmd; c.nsub[e] = L.nsub; c.flags[e] = L.fl;
 }

@@ -51,11 +51,13 @@ __device__ __forceinline__ void st_(void* base, uint32_t byte_off, const T& v)
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-// byte `idx` (0..15) of a 16-byte record held in registers, idx not known at compile time
-__device__ __forceinline__ uint32_t byte_of(const uint4& w, uint32_t idx)
+// byte `idx` (0..15) of a 16-byte record held in four registers, idx not known at compile time.  The words are
+// taken BY VALUE: selecting between the fields of a struct object is folded by the compiler into dynamic addressing
+// of a stack copy of it.
+__device__ __forceinline__ uint32_t byte_of(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t idx)
 {
-    const uint32_t lo = (idx & 4u) ? w.y : w.x;
-    const uint32_t hi = (idx & 4u) ? w.w : w.z;
+    const uint32_t lo = (idx & 4u) ? y : x;
+    const uint32_t hi = (idx & 4u) ? w : z;
     const uint32_t v = (idx & 8u) ? hi : lo;
     return (v >> ((idx & 3u) * 8u)) & 0xffu;
 }
@@ -137,34 +139,25 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     uint32_t k_bad = 0, k_steps = 0;
 
     // ---- per-env state loads (before anything is stored) ---------------------------------------
+    // Unconditional, from a clamped env index (lanes past N read env 0 and store nothing): as plain SSA values the
+    // 16-byte records stay in registers.  Loaded under `if (live)` into pre-initialised variables they became stack
+    // objects, and for some device counts the compiler then folded the byte selects below into dynamic addressing
+    // of such an object and moved it to LDS -- D = 3 and D = 6 ran three times slower than D = 4.
     const bool live = e < N;
-    const uint32_t o16 = e << 4;
-    const uint32_t oq = e * RB;
-    int d = 0, du = 0;
-    uint4 ip = make_uint4(0u, 0u, 0u, 0u), tk = ip, sa0 = ip, sa1 = ip;
+    const uint32_t el = live ? e : 0u;
+    const uint32_t o16 = e << 4, o16l = el << 4;
+    const uint32_t oq = e * RB, oql = el * RB;
+    const uint32_t o32 = e << 5, o32l = el << 5;
+    const int d = device[el];
+    const int du = duration[el];
+    const uint4 ip = ld<uint4>(st.ip, o16l);
+    const double2 tw = ld<double2>(st.tw, o16l);
+    const uint4 tk = ld<uint4>(st.tk, o16l);
     uint4 qw[NWC];
 #pragma unroll
-    for (int w = 0; w < NWC; ++w) qw[w] = ip;
-    uint32_t dyn_len = 0, dyn_sd = 0;                    // bytes of the record indexed by the action's device
-    const uint32_t o32 = e << 5;
-    double2 tw = make_double2(0.0, 0.0);
-    if (live) {
-        d = device[e];
-        du = duration[e];
-        ip = ld<uint4>(st.ip, o16);
-        tw = ld<double2>(st.tw, o16);
-        tk = ld<uint4>(st.tk, o16);
-        if (PACKED) {
-#pragma unroll
-            for (int w = 0; w < NWC; ++w) qw[w] = ld<uint4>(st.qb, oq + 16u * w);
-            if (NWC > 1 && (unsigned)d < (unsigned)DT) {  // dynamic index into a multi-word record: read the bytes directly
-                dyn_len = st.qb[oq + (uint32_t)d];
-                dyn_sd = st.qb[oq + (uint32_t)(DT + d)];
-            }
-        }
-        sa0 = ld<uint4>(st.sa, o32);
-        sa1 = ld<uint4>(st.sa, o32 + 16u);
-    }
+    for (int w = 0; w < NWC; ++w) qw[w] = PACKED ? ld<uint4>(st.qb, oql + 16u * w) : make_uint4(0u, 0u, 0u, 0u);
+    uint4 sa0 = ld<uint4>(st.sa, o32l);
+    uint4 sa1 = ld<uint4>(st.sa, o32l + 16u);
 
     // ---- constants -> registers, under the shadow of the loads above --------------------------------
     StepMath m(c);
@@ -230,11 +223,25 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             uint32_t len_d, s_d_old, s_r_old;
             if (PACKED) {
                 if (NWC == 1) {
-                    len_d = byte_of(qw[0], (uint32_t)d);
-                    s_d_old = byte_of(qw[0], (uint32_t)(DT + d));
-                } else {
-                    len_d = dyn_len;
-                    s_d_old = dyn_sd;
+                    // The record's words as opaque register values first: selecting between struct fields by a run-time
+                    // index is folded by the compiler into dynamic addressing of a stack copy of the record, which it then
+                    // moves to LDS -- whenever the index range straddles a word (D = 3, 6: three times slower than D = 4).
+                    uint32_t q0 = qw[0].x, q1 = qw[0].y, q2 = qw[0].z, q3 = qw[0].w;
+                    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+                    len_d = byte_of(q0, q1, q2, q3, (uint32_t)d);
+                    s_d_old = byte_of(q0, q1, q2, q3, (uint32_t)(DT + d));
+                } else {                                  // multi-word record: pick the word, then the byte, from registers
+                    uint32_t lx = 0, ly = 0, lz = 0, lw = 0, sx = 0, sy = 0, sz = 0, sw = 0;
+#pragma unroll
+                    for (int w = 0; w < NWC; ++w) {
+                        uint32_t q0 = qw[w].x, q1 = qw[w].y, q2 = qw[w].z, q3 = qw[w].w;
+                        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));      // opaque: see the one-word case
+                        const bool hl = ((uint32_t)d >> 4) == (uint32_t)w, hs = ((uint32_t)(DT + d) >> 4) == (uint32_t)w;
+                        lx = hl ? q0 : lx; ly = hl ? q1 : ly; lz = hl ? q2 : lz; lw = hl ? q3 : lw;
+                        sx = hs ? q0 : sx; sy = hs ? q1 : sy; sz = hs ? q2 : sz; sw = hs ? q3 : sw;
+                    }
+                    len_d = byte_of(lx, ly, lz, lw, (uint32_t)d & 15u);
+                    s_d_old = byte_of(sx, sy, sz, sw, (uint32_t)(DT + d) & 15u);
                 }
                 s_r_old = (word_of(qw[(2 * DT) >> 4], ((2 * DT) >> 2) & 3) >> (((2 * DT) & 3) * 8)) & 0xffu;
             } else {

@@ -494,6 +494,7 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
     case 2:  rc = launch_rollout<2>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 3:  rc = launch_rollout<3>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 4:  rc = launch_rollout<4>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
+    case 6:  rc = launch_rollout<6>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 8:  rc = launch_rollout<8>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 16: rc = launch_rollout<16>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     default: return GW_EUNSUPPORTED;

@@ -166,7 +166,7 @@ def test_invalid_action_is_flagged_and_env_left_untouched():
         one.step({"device": 0, "duration": 20})
 
 
-@pytest.mark.parametrize("D,N,K", [(2, 2048, 64), (4, 2048, 37), (4, 1024, 150), (16, 512, 48), (5, 256, 20), (4, 1001, 30), (8, 70, 64)])
+@pytest.mark.parametrize("D,N,K", [(2, 2048, 64), (4, 2048, 37), (4, 1024, 150), (16, 512, 48), (5, 256, 20), (4, 1001, 30), (8, 70, 64), (6, 512, 40)])
 def test_fused_rollout_matches_oracle(D, N, K):
     """gw_rollout: one persistent launch per <= 64 steps (free-running lanes, state in registers)
     must give exactly what K env.step() calls give -- outputs of every step and the final state.

@@ -30,21 +30,16 @@ using namespace gwk;
 namespace {
 
 
-// Rings are tiled ring[sender][env / 64][slot][env % 64].  head + len -- the slot an append goes to -- counts the appends
-// the queue has ever seen (a pop moves head up and len down, a drop likewise), and under counter traffic that count is
-// the same for every env of a launch: the 64 lanes of a wave append to 64 consecutive words (one 256-byte run instead of
-// 64 cache lines), and a lane's next append lands in the next run of the same 32 KB tile.  (Measured: env-major rings
-// 41 us per step, plain slot-major -- coalesced but each append 256 KB from the last -- 68 us.)
+// Rings are laid out SLOT-major, ring[sender][slot][env]: head + len -- the slot an append goes to -- counts the
+// appends the queue has ever seen (a pop moves head up and len down, a drop likewise), and under counter traffic that
+// count is the same for every env of a launch.  So the 64 lanes of a wave append to 64 consecutive words: ~90 coalesced
+// stores per env-step instead of ~90 stores to 64 different cache lines each.  Pops (a few per step) stay scattered.
 struct Ring {
     uint32_t* base;                                       // slot 0 of this (sender, env)
+    int64_t stride;                                       // elements between consecutive slots (= N)
     int head, len;
-    __device__ __forceinline__ uint32_t& at(int slot) const { return base[slot << 6]; }
+    __device__ __forceinline__ uint32_t& at(int slot) const { return base[(int64_t)slot * stride]; }
 };
-
-__device__ __forceinline__ uint32_t* ring_base(uint32_t* ring, int64_t tiles, int sender, int64_t e)
-{
-    return ring + (((int64_t)sender * tiles + (e >> 6)) << 13) + (e & 63);      // 128 slots x 64 lanes per tile
-}
 
 // one counter tick: counter_traffic.py:53-61 -> devices.py:84-86 -> simple_stack.py:463-471
 __device__ __forceinline__ void tick_append(Ring& r, uint32_t size, int mult, Tally& k)
@@ -145,8 +140,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             uint32_t ctr_d = ctr0;
             const uint16_t hl_d = st.qhl[(int64_t)d * N + e];
             Ring rd;
-            const int64_t tiles = (N + 63) >> 6;
-            rd.base = ring_base(st.ring, tiles, d, e);
+            rd.base = st.ring + ((int64_t)d << 7) * N + e;
+            rd.stride = N;
             rd.head = hl_d & 0xff;
             rd.len = hl_d >> 8;
             const int mult_d = c.mult[d];
@@ -222,7 +217,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 if (i == d) continue;
                 const uint16_t hl = st.qhl[(int64_t)i * N + e];
                 Ring ri;
-                ri.base = ring_base(st.ring, tiles, i, e);
+                ri.base = st.ring + ((int64_t)i << 7) * N + e;
+                ri.stride = N;
                 ri.head = hl & 0xff;
                 ri.len = hl >> 8;
                 // the same n_ticks ticks d's walk just counted (all senders tick together): no second pass over the
@@ -319,7 +315,8 @@ __global__ void ct_enqueue_kernel(GwState st, int sender, const int32_t* __restr
     const GwDevConst& c = *st.cst;
     const uint16_t hl = st.qhl[(int64_t)sender * N + e];
     Ring r;
-    r.base = ring_base(st.ring, (N + 63) >> 6, sender, e);
+    r.base = st.ring + ((int64_t)sender << 7) * N + e;
+    r.stride = N;
     r.head = hl & 0xff;
     r.len = hl >> 8;
     Tally k = {0, 0, 0, 0, 0};

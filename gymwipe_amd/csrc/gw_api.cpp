@@ -324,7 +324,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr; uint8_t* d_blob = nullptr;
     if (explicit_q) {
         TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
-        TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, ((N + 63) / 64 * 64) * D * GW_RING_PHYS);
+        TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
         TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
         TRY_ALLOC(st.rxs, N * R);
     } else {
@@ -395,7 +395,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
         HIP_TRY_D(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
     if (st.totals) HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
-    if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)((N + 63) / 64 * 64) * D * GW_RING_PHYS * sizeof(uint32_t)));
+    if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
     if (st.bph) HIP_TRY_D(hipMemset(st.bph, 0, (size_t)N * GW_RING_PHYS * sizeof(GwBp)));
     rc = explicit_q ? gw_launch_init(st, nullptr) : gw_launch_init_sfx(st, nullptr);
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
@@ -830,16 +830,15 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
             return GW_OK;
         }
         NEED(N * D * GW_QUEUE_CAP, uint32_t);
-        const size_t tiles = (size_t)(N + 63) / 64;
-        std::vector<uint32_t> ring(tiles * 64 * D * GW_RING_PHYS);
+        std::vector<uint32_t> ring((size_t)N * D * GW_RING_PHYS);
         HIP_TRY(hipMemcpy(ring.data(), st.ring, ring.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint32_t* o = (uint32_t*)dst;
         for (int64_t e = 0; e < N; ++e)
             for (int i = 0; i < D; ++i) {
                 const int head = hl[(size_t)i * N + e] & 0xff, len = hl[(size_t)i * N + e] >> 8;
-                const uint32_t* r = ring.data() + (((size_t)i * tiles + (size_t)(e >> 6)) << 13) + (e & 63);   // ring[sender][env/64][slot][env%64]
+                const uint32_t* r = ring.data() + ((size_t)i * GW_RING_PHYS) * N + e;       // ring[sender][slot][env]
                 uint32_t* q = o + ((size_t)e * D + i) * GW_QUEUE_CAP;
-                for (int s = 0; s < GW_QUEUE_CAP; ++s) q[s] = s < len ? r[(size_t)((head + s) & GW_RING_MASK) << 6] : 0u;
+                for (int s = 0; s < GW_QUEUE_CAP; ++s) q[s] = s < len ? r[(size_t)((head + s) & GW_RING_MASK) * N] : 0u;
             }
         return GW_OK;
     }

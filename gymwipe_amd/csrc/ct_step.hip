@@ -30,15 +30,9 @@ using namespace gwk;
 namespace {
 
 
-// Rings are laid out SLOT-major, ring[sender][slot][env]: head + len -- the slot an append goes to -- counts the
-// appends the queue has ever seen (a pop moves head up and len down, a drop likewise), and under counter traffic that
-// count is the same for every env of a launch.  So the 64 lanes of a wave append to 64 consecutive words: ~90 coalesced
-// stores per env-step instead of ~90 stores to 64 different cache lines each.  Pops (a few per step) stay scattered.
 struct Ring {
-    uint32_t* base;                                       // slot 0 of this (sender, env)
-    int64_t stride;                                       // elements between consecutive slots (= N)
+    uint32_t* base;
     int head, len;
-    __device__ __forceinline__ uint32_t& at(int slot) const { return base[(int64_t)slot * stride]; }
 };
 
 // one counter tick: counter_traffic.py:53-61 -> devices.py:84-86 -> simple_stack.py:463-471
@@ -50,7 +44,7 @@ __device__ __forceinline__ void tick_append(Ring& r, uint32_t size, int mult, Ta
             r.len--;
             k.drop++;
         }
-        r.at((r.head + r.len) & GW_RING_MASK) = size;
+        r.base[(r.head + r.len) & GW_RING_MASK] = size;
         r.len++;
         k.app++;
     }
@@ -140,8 +134,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             uint32_t ctr_d = ctr0;
             const uint16_t hl_d = st.qhl[(int64_t)d * N + e];
             Ring rd;
-            rd.base = st.ring + ((int64_t)d << 7) * N + e;
-            rd.stride = N;
+            rd.base = st.ring + (((int64_t)e * D + d) << 7);
             rd.head = hl_d & 0xff;
             rd.len = hl_d >> 8;
             const int mult_d = c.mult[d];
@@ -178,7 +171,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                             n_ticks++;
                         } else break;
                     }
-                    const uint32_t s = rd.at(rd.head);
+                    const uint32_t s = rd.base[rd.head];
                     const double need = m.over_rate((double)(s * 8u));    // messages.py:67-75
                     if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
                     rd.head = (rd.head + 1) & GW_RING_MASK;               // :425
@@ -217,8 +210,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 if (i == d) continue;
                 const uint16_t hl = st.qhl[(int64_t)i * N + e];
                 Ring ri;
-                ri.base = st.ring + ((int64_t)i << 7) * N + e;
-                ri.stride = N;
+                ri.base = st.ring + (((int64_t)e * D + i) << 7);
                 ri.head = hl & 0xff;
                 ri.len = hl >> 8;
                 // the same n_ticks ticks d's walk just counted (all senders tick together): no second pass over the
@@ -315,8 +307,7 @@ __global__ void ct_enqueue_kernel(GwState st, int sender, const int32_t* __restr
     const GwDevConst& c = *st.cst;
     const uint16_t hl = st.qhl[(int64_t)sender * N + e];
     Ring r;
-    r.base = st.ring + ((int64_t)sender << 7) * N + e;
-    r.stride = N;
+    r.base = st.ring + (((int64_t)e * c.D + sender) << 7);
     r.head = hl & 0xff;
     r.len = hl >> 8;
     Tally k = {0, 0, 0, 0, 0};

@@ -836,9 +836,9 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         for (int64_t e = 0; e < N; ++e)
             for (int i = 0; i < D; ++i) {
                 const int head = hl[(size_t)i * N + e] & 0xff, len = hl[(size_t)i * N + e] >> 8;
-                const uint32_t* r = ring.data() + ((size_t)i * GW_RING_PHYS) * N + e;       // ring[sender][slot][env]
+                const uint32_t* r = ring.data() + ((size_t)e * D + i) * GW_RING_PHYS;
                 uint32_t* q = o + ((size_t)e * D + i) * GW_QUEUE_CAP;
-                for (int s = 0; s < GW_QUEUE_CAP; ++s) q[s] = s < len ? r[(size_t)((head + s) & GW_RING_MASK) * N] : 0u;
+                for (int s = 0; s < GW_QUEUE_CAP; ++s) q[s] = s < len ? r[(head + s) & GW_RING_MASK] : 0u;
             }
         return GW_OK;
     }

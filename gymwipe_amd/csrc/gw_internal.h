@@ -47,7 +47,7 @@ struct GwState {
     // MAC queue (SimpleMac._packetQueue), one of two encodings:
     //  explicit (GW_CFG_EXPLICIT_QUEUE): a ring of packet byte sizes
     uint16_t* qhl;        // [D][N]     ring head (low byte) | length (high byte)
-    uint32_t* ring;       // [D][GW_RING_PHYS][N]  packet byte sizes, slot-major so that appends coalesce (ct_step.hip)
+    uint32_t* ring;       // [N][D][GW_RING_PHYS]  packet byte sizes
     //  suffix (default): see gw_queue.h.  Packed so that one env costs four 16-byte loads:
     double*   tw;         // [N][2]     {now, next counter tick}
     uint32_t* tk;         // [N][4]     {tau = ticks so far, nbp = breakpoints so far, newest breakpoint (t0, c0)}

@@ -152,8 +152,16 @@ class VecControlLoopEnv(BaseEnv):
             self._angle = torch.empty(n, dtype=torch.float64, device=self.device)
             self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
 
+    def reset(self):
+        """envs/inverted_pendulum.py:95-99: returns an observation, resets nothing."""
+        import math
+        if not self._stepped:                              # before the first step: the initial plant state
+            self._obs.fill_(int(math.degrees(self.config.x0[2])))
+        return self._obs
+
     def step(self, action):
         torch = self._torch
+        self._stepped = True
         dev = action["device"].to(device=self.device, dtype=torch.int32).contiguous()
         dur = action["duration"].to(device=self.device, dtype=torch.int32).contiguous()
         assert dev.shape == (self.num_envs,) and dur.shape == (self.num_envs,)

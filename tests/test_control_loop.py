@@ -67,7 +67,9 @@ def test_control_loop_env_surface():
     env = gymwipe_amd.make("VecControlLoop-v0", num_envs=1024)
     assert env.action_space.contains({"device": 1, "duration": 19}) and env.observation_space.n == 180
     z = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    assert (env.reset() == 2).all()                                    # int(degrees(0.05 rad)), nothing is reset
     obs, rew, done, info = env.step({"device": z, "duration": z + 7})
+    assert env.reset() is obs
     assert obs.shape == (1024,) and rew.dtype == torch.float32 and not done.any()
     env.step({"device": z + 2, "duration": z})                         # the actuator is not assignable: flagged, env untouched
     assert (env.get_state("flags") & 8).all()

@@ -151,6 +151,7 @@ class VecControlLoopEnv(BaseEnv):
             self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
             self._angle = torch.empty(n, dtype=torch.float64, device=self.device)
             self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._stepped = False
 
     def reset(self):
         """envs/inverted_pendulum.py:95-99: returns an observation, resets nothing."""

@@ -164,10 +164,10 @@ def main():
     acts = [{"device": a_dev[i], "duration": a_dur[i]} for i in range(W + K)]
 
     def one(i):
-        if i % RESET_EVERY == 0:
-            env.reset()
         if pipe is not None:                      # this step's outputs go into the current chunk record
             env._obs, env._rew, env._done = pipe.slot()
+        if i % RESET_EVERY == 0:
+            env.reset()                           # (its observation lands in the slot the step then overwrites)
         env.step(acts[i])
         if pipe is not None:
             pipe.stepped()                        # every 64th step: pack to bytes + async all-gather over RCCL

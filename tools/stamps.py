@@ -15,7 +15,6 @@ names = ["0 issue table+state loads, write LDS", "1 barrier", "2 state landed (t
          "4 announcement tx_times", "5 announcement decode, t_end", "6 window loop", "7 tail ticks_to(t_end)",
          "8 other senders + pack", "9 qb store", "10 feedback + stores", "11 counters store"]
 rows = []
-skew = []
 env.reset()
 for k in range(48):
     a = {"device": torch.randint(0, D, (N,), dtype=torch.int32, device="cuda", generator=g),
@@ -28,21 +27,10 @@ for k in range(48):
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         w = out[: N // 64].astype(np.int64)
         rows.append(np.diff(w[:, :13], axis=1))
-        # s_memtime counters are per XCD (workgroup i runs on XCD i % 8): offsets only make sense within one
-        st, en = [], []
-        for x in range(8):
-            wx = w[x::8]
-            t0 = wx[:, 0].min()
-            st.append(wx[:, 0] - t0)
-            en.append(wx[:, 12] - t0)
-        st, en = np.concatenate(st), np.concatenate(en)
-        skew.append((np.median(st), np.percentile(st, 99), st.max(), np.median(en), en.max()))
 d = np.concatenate(rows)
 print("cycles per wave (s_memtime ticks), median / p90 / mean over %d waves x %d launches" % (N // 64, len(rows)))
 for i, n in enumerate(names):
     print("  %-48s %8.0f %8.0f %8.0f" % (n, np.median(d[:, i]), np.percentile(d[:, i], 90), d[:, i].mean()))
 tot = d.sum(axis=1)
 print("  %-48s %8.0f %8.0f %8.0f" % ("total in-kernel", np.median(tot), np.percentile(tot, 90), tot.mean()))
-sk = np.array(skew)
-print("wave start / end relative to the first wave of the same XCD (ticks; median over launches of: median start, p99 start, "
-      "last start, median end, last end): %.0f %.0f %.0f %.0f %.0f" % tuple(np.median(sk, axis=0)))
+# (wave start/end offsets across the launch are not reported: s_memtime counters of different CUs are not comparable)

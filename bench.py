@@ -5,21 +5,31 @@ bench.py -- env.step()/s of the vectorised CounterTraffic band-assignment env on
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE env.step() of every environment of the batch: one launch of the HIP step
-kernel over 65 536 envs x 4 devices per GPU (BASELINE.json configs[1]).  Actions are
-synthetic (seeded uniform device/duration), generated on the GPU before the timed region;
-every env is reset() at step 0 and every 64 steps so the data-carrying phase stays in play
-(SURVEY.md 8d).  Rank 0 prints ONE JSON line.
+A "step" is ONE env.step() of every environment of the batch: one launch of the HIP step kernel over
+65 536 envs x 4 devices per GPU (BASELINE.json configs[1]).  Actions are synthetic: a counter-based
+generator (gymwipe_amd/actions.py: a pure function of seed, global env id and step index) evaluated on the
+GPU before the timed region and, identically, by the CPU baseline.
 
-  value        whole-job env-steps/s: N_gpus * envs_per_gpu * K / max-over-ranks wall time
-  roofline     HBM bound: algorithmic bytes per launch / average launch duration (HIP events on the
-               launch stream around the timed region, / K), against 8 TB/s.  Algorithmic bytes per env-step:
-               B(D) = 17 + 2*(12 + 20*D) + 4*(k_app + k_pop), k_app/k_pop counted by the kernel.
-  cpu_baseline the C oracle (scalar restatement of the reference algorithm, oracle/ct_oracle.c)
-               timed on this box's host cores on a bounded sample of the same workload
+One WINDOW is  reset() -> W untimed warm-up steps -> K timed steps  (reset again at every 64th step of a
+window, SURVEY.md 8d, so that the data-carrying phase stays in play).  The timed K steps are bracketed by
+barrier + torch.cuda.synchronize() on both sides.  Because K steps of a 7 us kernel are far too short to
+time once (the driver's --steps 20 is 0.2 ms), the window is REPEATED until >= 0.25 s of timed stream time
+have accumulated; every repeat starts from a reset, so every repeat times the same step indices after a
+reset (`timed_step_indices_after_reset`).  `value` = all env-steps of all timed regions / the sum over
+windows of the slowest rank's wall time.  Rank 0 prints ONE JSON line.
+
+  roofline     HBM bound.  `achieved` = SURVEY 8d's ALGORITHMIC bytes per launch / average launch duration (HIP events
+               on the launch stream around each timed region, / K), `frac` = achieved / 8 TB/s.  Algorithmic bytes per
+               env-step: B(D) = 17 + 2*(12 + 20*D) + 4*(k_app + k_pop), k_app/k_pop counted by the kernel.  Because the
+               kernel's queue encoding never materialises queue entries, the bytes it MOVES are fewer:
+               `frac_moved` = PMC traffic per launch (profiles/traffic.json, rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this
+               shape) / the same duration / peak, and `min_bytes_per_env_step` is the encoding's own read+write minimum.
+  cpu_baseline the C oracle (scalar restatement of the reference algorithm, oracle/ct_oracle.c) timed on this box's host
+               cores on a bounded sample of the same windows with the same action stream
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,6 +40,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 RESET_EVERY = 64
+SEED = 1234
+MIN_TIMED_S = 0.25         # timed stream time to accumulate over the repeated windows
+MAX_REPEATS = 20000
+MAX_WALL_S = 30.0          # bound on the whole repeated measurement
 
 
 def algorithmic_bytes(D, env_steps, appended, popped):
@@ -37,61 +51,76 @@ def algorithmic_bytes(D, env_steps, appended, popped):
 
 
 def state_bytes(D):
-    """Bytes the default kernel actually loads + stores per env-step."""
+    """Bytes the default kernel itself must load + store per env-step: the minimum of its encoding."""
     rb = 16 * ((2 * D + 1 + 15) // 16)
     return (16 + 16 + 16 + rb + 32 + 8) + (16 + 4 + 8 + rb + 32 + 9)
 
 
 def measured_traffic(D, N):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 for the gfx950
-    wide-load under-count + WRITE_SIZE, both in KB), if a profile of this exact shape is on file."""
+    wide-load under-count + WRITE_SIZE, both in KB) -- only if a profile of this exact shape is on file."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
             for row in json.load(fh)["rows"]:
-                if row["devices"] == D and row["envs"] == N:
-                    return (2 * row["fetch_kb"] + row["write_kb"]) * 1024.0
+                if row["devices"] == D and row["envs"] == N and row.get("kernel", "ct_step_sfx_kernel") == "ct_step_sfx_kernel":
+                    return (2 * row["fetch_kb"] + row["write_kb"]) * 1024.0, row.get("source", "profiles/traffic.json")
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline(D, seconds_target=12.0, single_thread_seconds=3.0):
-    """The oracle on the host cores, same action distribution, same reset cadence: all cores of the box's
-    CPU share for one GPU (the headline `value`) and one thread beside it."""
-    import numpy as np
-    from oracle.ct_oracle import CtOracle
+def host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))           # the GPU box's CPU share for one GPU
+    return max(1, cores)
 
-    def timed(nthreads, seconds):
-        n_env, K = 256 * nthreads, 64
-        rng = np.random.default_rng(1234)
-        dev = rng.integers(0, D, (K, n_env), dtype=np.int32)
-        dur = rng.integers(0, 20, (K, n_env), dtype=np.int32)
-        orc = CtOracle(n_env, D, nthreads=nthreads)
+
+def cpu_baseline(D, W, K, seconds_target=10.0, single_thread_seconds=2.5, other_devices=(2, 4, 16), other_seconds=2.0):
+    """The oracle on the host cores over the SAME windows (reset -> W + K steps, reset every 64) with the SAME counter-based
+    action stream (envs 0 .. n-1 of rank 0): all threads of this process's CPU share, one thread beside it, and short
+    samples for the other device counts of BASELINE's configs."""
+    from gymwipe_amd.actions import actions_numpy
+    from oracle.ct_oracle import CtOracle
+    nproc = host_cores()
+    cores = max(1, min(nproc, 16))           # the GPU box's CPU share for one GPU
+
+    def timed(dd, nthreads, seconds):
+        n_env = 256 * nthreads
+        dev, dur = actions_numpy(SEED, 0, n_env, 0, W + K, dd)
+        orc = CtOracle(n_env, dd, nthreads=nthreads)
         orc.reset()
-        for k in range(8):
+        for k in range(min(8, W + K)):
             orc.step(dev[k], dur[k])             # warm-up
         done_steps, t0 = 0, time.perf_counter()
         while True:
-            orc.reset()
-            for k in range(K):
+            for k in range(W + K):
+                if k % RESET_EVERY == 0:
+                    orc.reset()
                 orc.step(dev[k], dur[k])
-            done_steps += K * n_env
+            done_steps += (W + K) * n_env
             el = time.perf_counter() - t0
             if el >= seconds:
-                return done_steps / el, n_env, K, el
+                return done_steps / el, n_env, el
 
-    v, n_env, K, el = timed(cores, seconds_target)
-    v1, _, _, el1 = timed(1, single_thread_seconds)
-    return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d steps per pass (D=%d, reset every pass), repeated for %.1f s on %d threads (OpenMP)"
-                      % (n_env, K, D, el, cores),
-            "single_thread_value": v1, "single_thread_sample": "256 envs x %d steps per pass for %.1f s on 1 thread" % (K, el1)}
+    v, n_env, el = timed(D, cores, seconds_target)
+    v1, _, el1 = timed(D, 1, single_thread_seconds)
+    out = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port", "nproc": nproc,
+           "sample": "envs 0..%d of the GPU's action stream, windows of reset + %d steps (reset every %d), D=%d, repeated for %.1f s "
+                     "on %d threads (OpenMP)" % (n_env - 1, W + K, RESET_EVERY, D, el, cores),
+           "single_thread_value": v1,
+           "single_thread_sample": "envs 0..255, same windows, %.1f s on 1 thread" % el1}
+    by = {}
+    for dd in other_devices:
+        if dd == D:
+            by[str(dd)] = {"value": v, "cores": cores}
+        elif other_seconds > 0:
+            vv, _, _ = timed(dd, cores, other_seconds)
+            by[str(dd)] = {"value": vv, "cores": cores}
+    out["by_devices"] = by
+    return out
 
 
 def main():
@@ -99,22 +128,35 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)      # 64 warm-up + 1 024 timed steps
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65 536; 32 768 for --config 4)")
     ap.add_argument("--devices", type=int, default=4, help="senders per env (D)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4),
+                    help="BASELINE.json config: 2 = CounterTraffic D=4 (the headline), 3 = D=16, 4 = pendulum env (builder-defined plant)")
+    ap.add_argument("--repeats", type=int, default=0, help="windows to time (0 = as many as give %.2f s of timed stream time)" % MIN_TIMED_S)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="length of the CPU-baseline sample")
     ap.add_argument("--no-gather", action="store_true",
-                    help="N>1: skip the end-of-step observation gather (the only exchange of the path: one byte per "
-                         "env-step, one RCCL all-gather per 64 steps, overlapped with stepping)")
+                    help="N>1: skip the end-of-step observation gather (the only exchange of the path)")
     ap.add_argument("--no-rollout", action="store_true", help="skip the secondary fused-rollout measurement")
     ap.add_argument("--no-graph", action="store_true", help="skip the secondary hipGraph-replay measurement")
     ap.add_argument("--no-steady", action="store_true", help="skip the secondary no-reset steady-state measurement")
+    ap.add_argument("--no-secondaries", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
+    if args.no_secondaries:
+        args.no_rollout = args.no_graph = args.no_steady = True
+    if args.config == 3:
+        args.devices = 16
+    if args.config == 4:
+        import bench_pendulum                                    # tools-level module next to this file
+        return bench_pendulum.main(args)
+    if args.envs is None:
+        args.envs = 65536
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC for RCCL; must precede HIP initialisation
     import torch
     import torch.distributed as dist
     import gymwipe_amd
+    from gymwipe_amd.actions import actions_torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -134,13 +176,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev_t)
         else:
             dist.init_process_group(backend)
+    red_dev = dev_t if backend == "nccl" else "cpu"
 
     N, D, K, W = args.envs, args.devices, args.steps, args.warmup
     env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, device=dev_t)
 
-    # outputs as three views of ONE packed record buffer so that the end-of-step observation
+    # outputs as three views of ONE packed record buffer so that a per-step observation
     # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
-    from gymwipe_amd.sharding import ChunkedFeedbackGather, StepRecord
+    from gymwipe_amd.sharding import ChunkedFeedbackGather, ObservationGather, StepRecord
     pipe = None
     if world > 1 and not args.no_gather:
         if backend == "nccl":
@@ -157,10 +200,8 @@ def main():
     rec = StepRecord(N, dev_t)
     env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
 
-    g = torch.Generator(device=dev_t)
-    g.manual_seed(1234 + rank)
-    a_dev = torch.randint(0, D, (W + K, N), dtype=torch.int32, device=dev_t, generator=g)
-    a_dur = torch.randint(0, 20, (W + K, N), dtype=torch.int32, device=dev_t, generator=g)
+    # this rank's shard of the global action stream: envs [rank*N, (rank+1)*N), steps [0, W+K) of a window
+    a_dev, a_dur = actions_torch(SEED, rank * N, (rank + 1) * N, 0, W + K, D, device=dev_t)
     acts = [{"device": a_dev[i], "duration": a_dur[i]} for i in range(W + K)]
 
     def one(i):
@@ -172,76 +213,109 @@ def main():
         if pipe is not None:
             pipe.stepped()                        # every 64th step: pack to bytes + async all-gather over RCCL
 
-    for i in range(W):
-        one(i)
-    torch.cuda.synchronize()
-    s0 = env.stats()
-
-    # ---- timed region: exactly K steps -------------------------------------------------------
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def window(with_stats):
+        """reset -> W warm-up steps -> K timed steps; returns (wall s, stream s, stats delta or None)."""
+        for i in range(W):
+            one(i)
+        s0 = env.stats() if with_stats else None   # (synchronises)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(W, W + K):
+            one(i)
+        ev[1].record()
+        if pipe is not None:
+            pipe.drain()                              # the job is done when the last gather has landed
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        stream_s = ev[0].elapsed_time(ev[1]) * 1e-3
+        delta = None
+        if with_stats:
+            s1 = env.stats()
+            delta = {k: s1[k] - s0[k] for k in ("steps", "appended", "popped", "transmissions")}
+        return wall, stream_s, delta
+
+    # ---- calibration window (also the process warm-up): how many repeats give MIN_TIMED_S of timed stream time ----
+    window(False)
+    cal_wall, cal_stream, _ = window(False)
+    cal = torch.tensor([cal_stream, cal_wall], dtype=torch.float64, device=red_dev)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(W, W + K):
-        one(i)
-    ev[1].record()
-    if pipe is not None:
-        pipe.drain()                              # the job is done when the last gather has landed
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    s1 = env.stats()
+        dist.all_reduce(cal, op=dist.ReduceOp.MAX)
+    cal_stream, cal_wall = float(cal[0]), float(cal[1])
+    if args.repeats > 0:
+        R = args.repeats
+    else:
+        R = int(math.ceil(MIN_TIMED_S / max(cal_stream, 1e-6)))
+        per_window = cal_wall * (W + K) / max(K, 1) + 1e-3
+        R = max(1, min(R, MAX_REPEATS, int(MAX_WALL_S / per_window) or 1))
+    stat_stride = max(1, R // 32)
+
+    # ---- the measurement: R windows --------------------------------------------------------------------
+    walls, streams, deltas = [], [], []
+    for r in range(R):
+        wall, stream_s, delta = window(r % stat_stride == 0)
+        walls.append(wall)
+        streams.append(stream_s)
+        if delta is not None:
+            deltas.append(delta)
     env.check()
 
-    # the job's time is the slowest rank's; taken now so that the secondaries below contain no collective
-    t = torch.tensor([wall], dtype=torch.float64, device=dev_t if backend == "nccl" else "cpu")
+    # the job's time per window is the slowest rank's
+    t = torch.tensor(walls, dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    walls_max = t.cpu().tolist()
+    wall_total = sum(walls_max)
+    stream_total = sum(streams)
+    kern_avg_s = stream_total / (K * R)
+    # The K launches of a timed region run back-to-back on one stream, so (HIP event at the end - HIP event at the
+    # start) / K is the average launch duration including inter-kernel gaps and the reset kernel every 64 steps: an
+    # UPPER bound on the kernel's own time (event pairs around every launch add ~2.5 us each).
 
-    # ---- kernel duration --------------------------------------------------------------------------
-    # The K launches of the timed region run back-to-back on one stream (the GPU is the bottleneck),
-    # so (HIP event at the end - HIP event at the start) / K is the average launch duration including
-    # inter-kernel gaps and the reset kernel every 64 steps: an UPPER bound on the kernel's own time.
-    # (Event pairs around every launch were tried first: each pair adds ~2.5 us of its own.)
-    stream_s = ev[0].elapsed_time(ev[1]) * 1e-3
-    kern_avg_s = stream_s / K
-
-    # ---- secondaries (no collectives inside; a failure is reported in the JSON, it does not cost the headline) ----
+    # ---- secondaries (a failure is reported in the JSON, it does not cost the headline) ----
     def guarded(fn):
         try:
             return fn()
         except Exception as exc:
             return {"error": repr(exc)}
 
+    def best_of(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(n):
+            t1 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            best = el if best is None or el < best else best
+        return best
+
     def secondary_rollout():
-        """The same K steps through gw_rollout: one persistent launch per 64 pre-staged steps."""
+        """The same window through gw_rollout: one persistent launch per <= 64 pre-staged steps."""
         r_obs = torch.empty((RESET_EVERY, N), dtype=torch.int32, device=dev_t)
         r_rew = torch.empty((RESET_EVERY, N), dtype=torch.float32, device=dev_t)
         r_done = torch.empty((RESET_EVERY, N), dtype=torch.uint8, device=dev_t)
-        chunks = [(i, min(i + RESET_EVERY, W + K)) for i in range(W, W + K, RESET_EVERY)]
+        chunks = [(i, min(i + RESET_EVERY, W + K)) for i in range(0, W + K, RESET_EVERY)]
 
         def run_rollouts():
             for lo, hi in chunks:
-                if lo % RESET_EVERY == 0:
-                    env.reset()
+                env.reset()
                 env.rollout(a_dev[lo:hi], a_dur[lo:hi], out=(r_obs[:hi - lo], r_rew[:hi - lo], r_done[:hi - lo]))
-        run_rollouts()                                # warm-up
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_rollouts()
-        torch.cuda.synchronize()
-        roll_wall = time.perf_counter() - t1
+        roll_wall = best_of(run_rollouts)
         env.check()
-        return {"env_steps_per_s_this_rank": N * K / roll_wall, "ms_per_step": roll_wall / K * 1e3,
-                "what": "gw_rollout: one persistent launch per %d pre-staged steps (ct_rollout_sfx.hip), same K steps, "
-                        "same outputs; not the headline because env.step() is one call per step" % RESET_EVERY}
+        return {"env_steps_per_s_this_rank": N * (W + K) / roll_wall, "ms_per_step": roll_wall / (W + K) * 1e3,
+                "what": "gw_rollout: one persistent launch per <= %d pre-staged steps (ct_rollout_sfx.hip), the window's %d steps "
+                        "(warm-up included), same outputs; not the headline because env.step() is one call per step" % (RESET_EVERY, W + K)}
 
     def secondary_graph():
-        """The same K gw_step launches replayed from a hipGraph of reset + 64 steps."""
+        """The window's launches replayed from a hipGraph of reset + 64 steps."""
         G = RESET_EVERY
         g_dev = torch.zeros((G, N), dtype=torch.int32, device=dev_t)
         g_dur = torch.zeros((G, N), dtype=torch.int32, device=dev_t)
@@ -254,78 +328,136 @@ def main():
                 env.step({"device": g_dev[j], "duration": g_dur[j]})
 
         def run_graphs():
-            for lo in range(W, W + K, G):
+            for lo in range(0, W + K, G):
                 g_dev.copy_(a_dev[lo:lo + G])
                 g_dur.copy_(a_dur[lo:lo + G])
                 graph.replay()
-        run_graphs()                                  # warm-up
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        run_graphs()
-        torch.cuda.synchronize()
-        g_wall = time.perf_counter() - t2
+        g_wall = best_of(run_graphs)
         env.check()
-        return {"env_steps_per_s_this_rank": N * K / g_wall, "ms_per_step": g_wall / K * 1e3,
-                "what": "the same K gw_step launches replayed from a hipGraph of reset + %d steps (launch-bound "
-                        "host loop removed; includes the copy of each chunk's actions into the graph's input buffers)" % G}
+        return {"env_steps_per_s_this_rank": N * (W + K) / g_wall, "ms_per_step": g_wall / (W + K) * 1e3,
+                "what": "the window's gw_step launches replayed from a hipGraph of reset + %d steps (host launch loop removed; "
+                        "includes the copy of each chunk's actions into the graph's input buffers)" % G}
 
     def secondary_steady():
         """Steady state without resets (SURVEY 8d asks for it separately): after ~0.2 s of simulated time the
         packets have outgrown every window and steps carry no data any more."""
         env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
-        n_ss = min(256, K)
-        for i in range(W, W + min(64, K)):
-            env.step(acts[i])
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for i in range(W, W + n_ss):
-            env.step(acts[i])
-        torch.cuda.synchronize()
-        ss_wall = time.perf_counter() - t3
+        n_ss = max(64, min(256, W + K))
+        for j in range(64):
+            env.step(acts[j % (W + K)])
+
+        def run():
+            for j in range(n_ss):
+                env.step(acts[j % (W + K)])
+        ss_wall = best_of(run, 3)
         return {"env_steps_per_s_this_rank": N * n_ss / ss_wall, "ms_per_step": ss_wall / n_ss * 1e3, "steps": n_ss,
                 "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "
                         "for any window, so a step is the announcement plus counter ticks"}
 
+    def secondary_per_step_gather():
+        """The literal end-of-step gather north_star names: every step's 9*N-byte (obs, reward, done) record all-gathered
+        before the next step is launched."""
+        env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
+        if backend == "nccl":
+            gather = ObservationGather(rec, world)
+            go = gather
+        else:                                                    # rehearsal: host-side collective
+            host_rec = torch.zeros(rec.nbytes, dtype=torch.uint8)
+            host_out = torch.zeros(world * rec.nbytes, dtype=torch.uint8)
+
+            def go():
+                host_rec.copy_(rec.buf)
+                dist.all_gather_into_tensor(host_out, host_rec)
+
+        def run():
+            for i in range(W + K):
+                if i % RESET_EVERY == 0:
+                    env.reset()
+                env.step(acts[i])
+                go()
+        run()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        el = float(el.item())
+        return {"env_steps_per_s": world * N * (W + K) / el, "ms_per_step": el / (W + K) * 1e3,
+                "bytes_per_rank_per_step": rec.nbytes,
+                "what": "one all_gather_into_tensor of the 9*N-byte step record per env.step(), issued on the step's stream "
+                        "(every rank sees every observation before the next step); the headline uses the chunked form "
+                        "(1 byte per env-step, one all-gather per %d steps, overlapped)" % RESET_EVERY}
+
+    per_step = guarded(secondary_per_step_gather) if (world > 1 and not args.no_gather) else None
     roll = guarded(secondary_rollout) if not args.no_rollout else None
     # graph replay at N = 1 only: stream capture next to a live RCCL communicator (whose watchdog thread queries
     # events) is a needless risk for a secondary figure
-    graph_sec = (guarded(secondary_graph)
-                 if (not args.no_graph and world == 1 and K % RESET_EVERY == 0 and W % RESET_EVERY == 0) else None)
+    graph_sec = guarded(secondary_graph) if (not args.no_graph and world == 1 and (W + K) % RESET_EVERY == 0) else None
     steady = guarded(secondary_steady) if not args.no_steady else None
 
     if rank == 0:
-        env_steps = s1["steps"] - s0["steps"]
-        bytes_launch = algorithmic_bytes(D, env_steps, s1["appended"] - s0["appended"],
-                                         s1["popped"] - s0["popped"]) / K
+        n_st = max(1, len(deltas))
+        env_steps = sum(d["steps"] for d in deltas) / n_st
+        app = sum(d["appended"] for d in deltas) / n_st
+        pop = sum(d["popped"] for d in deltas) / n_st
+        txs = sum(d["transmissions"] for d in deltas) / n_st
+        bytes_launch = algorithmic_bytes(D, env_steps, app, pop) / K
         achieved = bytes_launch / kern_avg_s
-        value = world * N * K / wall_max
+        value = world * N * K * R / wall_total
+        traffic, traffic_src = measured_traffic(D, N)
+        us = [w / K * 1e6 for w in walls_max]
+        us_stream = [s / K * 1e6 for s in streams]
+        lo, hi = W % RESET_EVERY, (W % RESET_EVERY) + K - 1
+        roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": traffic,
+                "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this shape; FETCH_SIZE x 2 for "
+                                   "the gfx950 wide-load under-count; not measured in this run)") if traffic else None,
+                "frac_moved": (traffic / kern_avg_s / HBM_PEAK) if traffic else None,
+                "min_bytes_per_env_step": state_bytes(D),
+                "frac_min_bytes": state_bytes(D) * N / kern_avg_s / HBM_PEAK,
+                "kernel": "ct_step_sfx_kernel", "kernel_avg_us": kern_avg_s * 1e6,
+                "how": "HIP events on the launch stream around each window's K timed launches, summed over the %d windows, / (K * windows) "
+                       "(upper bound on the kernel's own duration: includes inter-launch gaps and the reset kernel every %d steps)"
+                       % (R, RESET_EVERY),
+                "algorithmic_bytes_per_launch": bytes_launch,
+                "algorithmic_bytes_per_env_step": bytes_launch / N,
+                "transmissions_per_env_step": txs / max(env_steps, 1),
+                "note": "frac prices the launch at SURVEY 8d's algorithmic bytes (4 B per queue entry appended or popped). The kernel's "
+                        "suffix queue encoding never materialises those entries: it loads and stores min_bytes_per_env_step per env-step "
+                        "(frac_min_bytes), and frac_moved is the PMC-measured HBM traffic over the same duration. By bytes actually moved "
+                        "the launch is latency-bound, not bandwidth-bound (one wave per SIMD at 65 536 envs; profiles/)."}
+        if roof["frac"] > 1.0:
+            roof["frac_above_one_because"] = ("algorithmic bytes (%.0f B per env-step, mostly 4 B x %.0f queue appends) exceed what the suffix "
+                                              "encoding moves (%d B per env-step): 8d's byte model does not bound this implementation at "
+                                              "D = %d; read frac_moved / frac_min_bytes" % (bytes_launch / N, app / max(env_steps, 1), state_bytes(D), D))
         out = {
             "metric": "env.step()/s at 65 536 parallel envs, counter-traffic band-assign",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall_max / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall_total / (K * R) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": R,
+            "timed_step_indices_after_reset": [lo, hi] if hi < RESET_EVERY else [lo, hi, "reset again every %d steps" % RESET_EVERY],
+            "us_per_step": {"min": min(us), "mean": sum(us) / len(us), "max": max(us),
+                            "stream_min": min(us_stream), "stream_mean": sum(us_stream) / len(us_stream), "stream_max": max(us_stream)},
+            "timed_stream_s": stream_total, "timed_wall_s": wall_total,
             "config": {"workload": "CounterTrafficEnv, %d devices, %d vectorised envs per GPU, reset every %d steps"
                                    % (D, N, RESET_EVERY),
                        "envs_per_gpu": N, "devices": D, "global_envs": world * N,
+                       "window": "reset -> %d warm-up steps -> %d timed steps, repeated %d times; each timed region bracketed by "
+                                 "barrier + synchronize; value = env-steps of all timed regions / sum of their wall times" % (W, K, R),
+                       "actions": "counter-based generator, seed %d (gymwipe_amd/actions.py), identical for the CPU baseline" % SEED,
                        "obs_gather": pipe is not None,
                        "parallelism": "independent env shards, one process per GPU; only exchange: end-of-step feedback "
                                       "gather, 1 byte per env-step, one RCCL all-gather per %d steps overlapped with stepping"
                                       % RESET_EVERY,
-                       "launches_per_step": 1, "stream_ms_per_step": stream_s / K * 1e3},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": measured_traffic(D, N),
-                         "kernel": "ct_step_sfx_kernel", "kernel_avg_us": kern_avg_s * 1e6,
-                         "how": "HIP events around the K timed launches on the launch stream / K (upper bound: includes gaps)",
-                         "algorithmic_bytes_per_launch": bytes_launch,
-                         "algorithmic_bytes_per_env_step": bytes_launch / N,
-                         "state_bytes_per_env_step": state_bytes(D),
-                         "note": "achieved uses SURVEY 8d's algorithmic bytes (4 B per queue entry appended/popped); "
-                                 "the suffix queue encoding never materialises those entries, so measured HBM traffic "
-                                 "(traffic, rocprofv3 PMC, profiles/) is BELOW the algorithmic bytes; by bytes actually moved the "
-                                 "launch runs at ~25% of HBM peak and is bound by latency: one wave per SIMD, every wave in the same "
-                                 "phase (load burst, serial per-env walk, store burst), 63% of wave cycles in s_waitcnt "
-                                 "(profiles/r1_final/SUMMARY.txt)"},
+                       "launches_per_step": 1, "stream_ms_per_step": kern_avg_s * 1e3},
+            "roofline": roof,
         }
+        if per_step is not None:
+            out["per_step_gather"] = per_step
         if roll is not None:
             out["fused_rollout"] = roll
         if graph_sec is not None:
@@ -333,7 +465,8 @@ def main():
         if steady is not None:
             out["steady_state_no_reset"] = steady
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (the other ranks would idle)
-            out["cpu_baseline"] = cpu_baseline(D, args.cpu_seconds, min(3.0, args.cpu_seconds / 4))
+            cs = args.cpu_seconds
+            out["cpu_baseline"] = cpu_baseline(D, W, K, cs, min(2.5, cs / 4), other_seconds=min(2.0, cs / 5))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where the host's time goes around one env.step(): per-call enqueue cost (Python + ctypes + hipLaunchKernel), and the
+latency of torch.cuda.synchronize() after the last launch.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gymwipe_amd
+from gymwipe_amd.actions import actions_torch
+
+out = {}
+for N in (64, 65536):
+    env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=4)
+    a_dev, a_dur = actions_torch(1234, 0, N, 0, 64, 4, device="cuda")
+    acts = [{"device": a_dev[i], "duration": a_dur[i]} for i in range(64)]
+    env.reset()
+    for i in range(64):
+        env.step(acts[i])
+    torch.cuda.synchronize()
+    # (a) enqueue cost: K calls, clock stopped BEFORE the synchronize
+    best_enq, best_tot = 1e9, 1e9
+    for rep in range(20):
+        env.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(20):
+            env.step(acts[i + 5])
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        best_enq = min(best_enq, (t1 - t0) / 20)
+        best_tot = min(best_tot, (t2 - t0) / 20)
+    out["N=%d" % N] = {"enqueue_us_per_step": best_enq * 1e6, "wall_us_per_step_incl_sync": best_tot * 1e6}
+    # (b) one launch + synchronize
+    lat = []
+    for rep in range(50):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        env.step(acts[40])
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    out["N=%d" % N]["single_step_launch_to_sync_us_median"] = lat[len(lat) // 2] * 1e6
+    out["N=%d" % N]["single_step_launch_to_sync_us_min"] = lat[0] * 1e6
+    env.close()
+t0 = time.perf_counter()
+for _ in range(1000):
+    torch.cuda.synchronize()
+out["empty_synchronize_us"] = (time.perf_counter() - t0) / 1000 * 1e6
+print(json.dumps(out))

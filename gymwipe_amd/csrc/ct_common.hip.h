@@ -79,32 +79,30 @@ __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 l
 //   * eight global atomics per wave on ONE shared line serialised the whole launch (~90 us);
 //   * eight 64-lane shuffle reductions + load/add/store of the private slot: 43% of a wave's cycles;
 //   * three packed shuffle reductions + atomics on the private line: still ~2.1k cycles per wave.
-// Now: the per-lane counters are packed into three words, summed by LDS atomics (one ds_add per
-// word for the whole wave), and lanes 0..7 issue ONE global atomic instruction on the wave's line.
+// Now: the per-lane counters go into seven words summed by LDS atomics (one ds_add per word for the whole
+// wave), and lanes 0..7 issue ONE global atomic instruction on the wave's line.  Appends and drops get a full
+// 32-bit word each (64 lanes x 21 ticks x multiplicity 100 = 134 400 per wave does not fit 16 bits).
 __device__ __forceinline__ void publish_totals(unsigned long long* totals, const Tally& k, uint32_t k_steps,
                                                uint32_t k_bad, uint32_t fl_new)
 {
-    __shared__ uint32_t s_acc[4][4];                    // [wave in block][word]
+    __shared__ uint32_t s_acc[4][8];                    // [wave in block][word]
     const uint32_t lane = threadIdx.x & 63u, wv = (threadIdx.x >> 6) & 3u;
-    if (lane < 4u) s_acc[wv][lane] = 0u;                // same wave, in-order LDS: no barrier needed
-    // wave sums: tx, deliv, pop < 2^10 each; app, drop < 2^15 each; steps, bad <= 64 each
-    atomicAdd(&s_acc[wv][0], k.tx | (k.deliv << 10) | (k.pop << 20));
-    atomicAdd(&s_acc[wv][1], k.app | (k.drop << 16));
-    atomicAdd(&s_acc[wv][2], k_steps | (k_bad << 8));
-    atomicOr(&s_acc[wv][3], fl_new);
+    if (lane < 8u) s_acc[wv][lane] = 0u;                // same wave, in-order LDS: no barrier needed
+    // every event count gets a full 32-bit word (a lane can pop hundreds of packets per step at a high bit rate);
+    // steps, bad <= 64 each share one
+    atomicAdd(&s_acc[wv][GW_T_TX], k.tx);
+    atomicAdd(&s_acc[wv][GW_T_DELIV], k.deliv);
+    atomicAdd(&s_acc[wv][GW_T_POP], k.pop);
+    atomicAdd(&s_acc[wv][GW_T_APP], k.app);
+    atomicAdd(&s_acc[wv][GW_T_DROP], k.drop);
+    atomicAdd(&s_acc[wv][GW_T_STEPS], k_steps | (k_bad << 8));
+    atomicOr(&s_acc[wv][GW_T_FLAGS], fl_new);
     if (lane < (uint32_t)GW_T_COUNT) {
-        const uint32_t a = s_acc[wv][0], b = s_acc[wv][1], c = s_acc[wv][2], f = s_acc[wv][3];
-        unsigned long long v = 0;
-        switch (lane) {
-        case GW_T_STEPS: v = c & 0xffu; break;
-        case GW_T_TX:    v = a & 0x3ffu; break;
-        case GW_T_DELIV: v = (a >> 10) & 0x3ffu; break;
-        case GW_T_APP:   v = b & 0xffffu; break;
-        case GW_T_POP:   v = (a >> 20) & 0x3ffu; break;
-        case GW_T_DROP:  v = b >> 16; break;
-        case GW_T_BAD:   v = (c >> 8) & 0xffu; break;
-        default:         v = 0; break;                  // GW_T_FLAGS handled below
-        }
+        const uint32_t w = s_acc[wv][lane == (uint32_t)GW_T_BAD ? (uint32_t)GW_T_STEPS : lane];
+        unsigned long long v = w;
+        if (lane == (uint32_t)GW_T_STEPS) v = w & 0xffu;
+        if (lane == (uint32_t)GW_T_BAD) v = w >> 8;
+        const uint32_t f = w;
         const size_t waves_per_block = (blockDim.x + 63) >> 6;
         const size_t wave = (size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
         unsigned long long* t = totals + wave * GW_T_COUNT;

@@ -30,40 +30,69 @@ using namespace gwk;
 namespace {
 
 
+// One sender's ring during a step.  Appends are never stored one by one: every packet a counter tick appends has the
+// size base + min(ctr0 + tick, bound), so the entries appended in this step are arithmetic in their index and are
+// written once, at the end of the step, as whole 16-byte stores (q_flush).  head/len move as the deque's would.
 struct Ring {
     uint32_t* base;
-    int head, len;
+    uint32_t head, len, app;           // app: entries appended in this step so far (not yet in memory)
 };
 
-// one counter tick: counter_traffic.py:53-61 -> devices.py:84-86 -> simple_stack.py:463-471
-__device__ __forceinline__ void tick_append(Ring& r, uint32_t size, int mult, Tally& k)
+// k counter ticks of a sender with multiplicity `mult` (counter_traffic.py:53-61 -> devices.py:84-86 ->
+// simple_stack.py:463-471): drop-oldest on a full deque is the min(), the head moves by the number of drops
+__device__ __forceinline__ void ring_ticks(Ring& r, uint32_t k, uint32_t mult, Tally& t)
 {
-    for (int m = 0; m < mult; ++m) {
-        if (r.len == GW_QUEUE_CAP) {                      // deque(maxlen=100): drop the oldest
-            r.head = (r.head + 1) & GW_RING_MASK;
-            r.len--;
-            k.drop++;
-        }
-        r.base[(r.head + r.len) & GW_RING_MASK] = size;
-        r.len++;
-        k.app++;
-    }
+    const uint32_t add = k * mult;
+    const uint32_t want = r.len + add;
+    const uint32_t now = want < (uint32_t)GW_QUEUE_CAP ? want : (uint32_t)GW_QUEUE_CAP;
+    const uint32_t drops = want - now;
+    r.head = (r.head + drops) & GW_RING_MASK;
+    r.len = now;
+    r.app += add;
+    t.app += add;
+    t.drop += drops;
 }
 
-// all ticks with wake < t (or <= t when inclusive); wake/ctr advance in place; n_ticks counts them
-__device__ __forceinline__ void ticks_until(Ring& r, double& wake, uint32_t& ctr, double t, bool inclusive,
-                                            int mult, uint32_t base_bytes, uint32_t bound, double interval,
-                                            Tally& k, uint32_t& flags, uint32_t& n_ticks)
+// size of the head packet.  The queue is the last `len` packets of the sender's append stream and this step's appends
+// are its last `app`: the head is one of them iff len <= app (then it is append number app - len, of tick
+// (app - len) / mult); otherwise it is in memory.
+__device__ __forceinline__ uint32_t ring_head_size(const Ring& r, uint32_t inv20, uint32_t ctr0, uint32_t bound, uint32_t base_bytes)
 {
-    for (;;) {
-        const double w = wake;
-        if (w < t || (inclusive && w == t)) {
-            if (w == t) flags |= GW_FLAG_TIE;
-            tick_append(r, base_bytes + ctr, mult, k);
-            if (ctr < bound) ctr++;
-            wake = w + interval;                          // running sum, not k*dt
-            n_ticks++;
-        } else break;
+    if (r.len <= r.app) {
+        const uint32_t tick = ((r.app - r.len) * inv20) >> 20;      // exact: (app - len) * mult < 2^20
+        const uint32_t v = ctr0 + tick;
+        return base_bytes + (v < bound ? v : bound);
+    }
+    return r.base[r.head];
+}
+
+// write this step's appends: entry p (0-based) sits in slot (tail0 + p) & mask and holds base + min(ctr0 + p / mult, bound).
+// Aligned groups of four go out as one 16-byte store (the ring is 128 entries, so a group never wraps).
+__device__ __forceinline__ void ring_flush(uint32_t* ring, uint32_t tail0, uint32_t app, uint32_t mult, uint32_t inv20,
+                                           uint32_t ctr0, uint32_t bound, uint32_t base_bytes)
+{
+    uint32_t p = app > (uint32_t)GW_RING_PHYS ? app - (uint32_t)GW_RING_PHYS : 0u;   // older ones would be overwritten anyway
+    uint32_t t = (p * inv20) >> 20;                       // p / mult
+    uint32_t rem = mult - (p - t * mult);                 // copies of tick t still to write
+    uint32_t slot = (tail0 + p) & GW_RING_MASK;
+    auto next = [&]() {
+        const uint32_t v = ctr0 + t;
+        const uint32_t out = base_bytes + (v < bound ? v : bound);
+        if (--rem == 0u) { ++t; rem = mult; }
+        return out;
+    };
+    while (p < app) {
+        if ((slot & 3u) == 0u && app - p >= 4u) {
+            uint4 v;
+            v.x = next(); v.y = next(); v.z = next(); v.w = next();
+            *reinterpret_cast<uint4*>(ring + slot) = v;
+            p += 4u;
+            slot = (slot + 4u) & GW_RING_MASK;
+        } else {
+            ring[slot] = next();
+            p += 1u;
+            slot = (slot + 1u) & GW_RING_MASK;
+        }
     }
 }
 
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const int mh = c.mac_hdr;
 
             const double t_a = st.now[e];
-            const double wake0 = st.wake[e];
+            double wake = st.wake[e];
             const uint32_t ctr0 = st.counter[e];
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
@@ -130,14 +159,15 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
             // ---- A.3: window at sender d -----------------------------------------------
-            double wake_d = wake0;
-            uint32_t ctr_d = ctr0;
             const uint16_t hl_d = st.qhl[(int64_t)d * N + e];
             Ring rd;
             rd.base = st.ring + (((int64_t)e * D + d) << 7);
-            rd.head = hl_d & 0xff;
+            rd.head = hl_d & 0xffu;
             rd.len = hl_d >> 8;
-            const int mult_d = c.mult[d];
+            rd.app = 0u;
+            const uint32_t tail0_d = (rd.head + rd.len) & GW_RING_MASK;
+            const uint32_t mult_d = (uint32_t)c.mult[d];
+            const uint32_t inv20_d = c.inv20[d];
             int n_data = 0;
             uint32_t n_ticks = 0;                                         // counter ticks inside this step
             uint8_t s_r = 0;
@@ -153,28 +183,46 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 s_p = st.trans[((int64_t)j_peer * R + RRM) * S + s_p_old];    // it heard the announcement too
             }
 
+            // all counter ticks with wake < t (or <= t): counted in f64 four at a time (the running sum w += dt is the
+            // reference's arithmetic, counter_traffic.py:61), applied to d's queue in one go
+            auto ticks_to = [&](double t, bool inclusive) {
+                uint32_t kk = 0;
+                for (;;) {
+                    const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
+                    const bool b0 = inclusive ? (wake <= t) : (wake < t);
+                    const bool b1 = inclusive ? (w1 <= t) : (w1 < t);
+                    const bool b2 = inclusive ? (w2 <= t) : (w2 < t);
+                    const bool b3 = inclusive ? (w3 <= t) : (w3 < t);
+                    if (inclusive && (wake == t || w1 == t || w2 == t || w3 == t)) fl |= GW_FLAG_TIE;
+                    const uint32_t n = (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;   // monotone
+                    wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
+                    kk += n;
+                    if (!b3) break;
+                }
+                n_ticks += kk;
+                ring_ticks(rd, kk, mult_d, k);
+            };
+
             if (granted) {
                 const double total = (double)slots * slot;               // simple_stack.py:400
                 const double stopw = t_r + total;                        // :401 (== timeout time :406)
                 double cur = t_r;
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
-                ticks_until(rd, wake_d, ctr_d, cur, false, mult_d, base_bytes, bound, interval, k, fl, n_ticks);
+                ticks_to(cur, false);
                 for (;;) {
-                    if (rd.len == 0) {                                    // :409-416
-                        const double w = wake_d;
+                    if (rd.len == 0u) {                                   // :409-416
                         // (a silent sender, mult 0, never signals packet-added: the MAC waits for the timeout)
-                        if (mult_d > 0 && w < stopw) {
-                            cur = w;
-                            tick_append(rd, base_bytes + ctr_d, mult_d, k);
-                            if (ctr_d < bound) ctr_d++;
-                            wake_d = w + interval;
+                        if (mult_d > 0u && wake < stopw) {
+                            cur = wake;
+                            wake = wake + interval;
                             n_ticks++;
+                            ring_ticks(rd, 1u, mult_d, k);
                         } else break;
                     }
-                    const uint32_t s = rd.base[rd.head];
+                    const uint32_t s = ring_head_size(rd, inv20_d, ctr0, bound, base_bytes);
                     const double need = m.over_rate((double)(s * 8u));    // messages.py:67-75
                     if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
-                    rd.head = (rd.head + 1) & GW_RING_MASK;               // :425
+                    rd.head = (rd.head + 1u) & GW_RING_MASK;              // :425
                     rd.len--;
                     k.pop++;
                     const int pay = (int)s - mh;
@@ -197,32 +245,48 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
                     // ticks are older events than the MAC's resume at t_e: they go first
-                    ticks_until(rd, wake_d, ctr_d, x.t_e, true, mult_d, base_bytes, bound, interval, k, fl, n_ticks);
+                    ticks_to(x.t_e, true);
                     cur = x.t_e;
                     if (!(cur < stopw)) break;                            // window timeout already processed
                 }
             }
 
-            // ---- A.5: remaining ticks up to the end of the step ----------------------------
-            ticks_until(rd, wake_d, ctr_d, t_end, true, mult_d, base_bytes, bound, interval, k, fl, n_ticks);
+            // ---- A.5: remaining ticks up to the end of the step: in one jump (gw_fastmath.h; exact, validated at
+            //      gw_create) or, where the jump declines, by the loop ----------------------------
+            {
+                uint32_t nj = 0;
+                double wj = wake;
+                bool tiej = false;
+                if (c.fast_ticks && gw_tick_jump(wake, t_end, interval, c.inv_interval, true, &nj, &wj, &tiej)) {
+                    wake = wj;
+                    n_ticks += nj;
+                    if (tiej) fl |= GW_FLAG_TIE;
+                    ring_ticks(rd, nj, mult_d, k);
+                } else {
+                    ticks_to(t_end, true);
+                }
+            }
             st.qhl[(int64_t)d * N + e] = (uint16_t)(rd.head | (rd.len << 8));
+            ring_flush(rd.base, tail0_d, rd.app, mult_d, inv20_d, ctr0, bound, base_bytes);
             for (int i = 0; i < D; ++i) {
                 if (i == d) continue;
+                // the same n_ticks ticks d's walk just counted (all senders tick together)
                 const uint16_t hl = st.qhl[(int64_t)i * N + e];
                 Ring ri;
                 ri.base = st.ring + (((int64_t)e * D + i) << 7);
-                ri.head = hl & 0xff;
+                ri.head = hl & 0xffu;
                 ri.len = hl >> 8;
-                // the same n_ticks ticks d's walk just counted (all senders tick together): no second pass over the
-                // f64 tick times, only the appends
-                uint32_t ct = ctr0;
-                const int mult_i = c.mult[i];
-                for (uint32_t n = 0; n < n_ticks; ++n) {
-                    tick_append(ri, base_bytes + ct, mult_i, k);
-                    if (ct < bound) ct++;
+                ri.app = 0u;
+                const uint32_t tail0 = (ri.head + ri.len) & GW_RING_MASK;
+                const uint32_t mult_i = (uint32_t)c.mult[i];
+                if (n_ticks != 0u && mult_i != 0u) {
+                    ring_ticks(ri, n_ticks, mult_i, k);
+                    st.qhl[(int64_t)i * N + e] = (uint16_t)(ri.head | (ri.len << 8));
+                    ring_flush(ri.base, tail0, ri.app, mult_i, c.inv20[i], ctr0, bound, base_bytes);
                 }
-                st.qhl[(int64_t)i * N + e] = (uint16_t)(ri.head | (ri.len << 8));
             }
+            uint32_t ctr_new = ctr0 + n_ticks;                            // `if counter < bound: counter += 1` per tick
+            ctr_new = (ctr0 >= bound) ? ctr0 : (ctr_new < bound ? ctr_new : bound);
 
             // ---- rx-power state of every radio (simple_stack.py:130-157) ---------------------
             if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
@@ -255,8 +319,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             done[e] = dn;
 
             st.now[e] = t_end;
-            st.wake[e] = wake_d;
-            st.counter[e] = ctr_d;
+            st.wake[e] = wake;
+            st.counter[e] = ctr_new;
             st.rvmask[e] = rvm;
             st.last_abs[e] = last_abs;
             st.done[e] = dn;
@@ -306,14 +370,17 @@ __global__ void ct_enqueue_kernel(GwState st, int sender, const int32_t* __restr
     if (pb < 0) return;
     const GwDevConst& c = *st.cst;
     const uint16_t hl = st.qhl[(int64_t)sender * N + e];
-    Ring r;
-    r.base = st.ring + (((int64_t)e * c.D + sender) << 7);
-    r.head = hl & 0xff;
-    r.len = hl >> 8;
-    Tally k = {0, 0, 0, 0, 0};
-    tick_append(r, (uint32_t)(c.mac_hdr + c.net_hdr + pb), 1, k);
-    st.qhl[(int64_t)sender * N + e] = (uint16_t)(r.head | (r.len << 8));
-    if (st.pe_stats) { st.pe_stats[2 * N + e] += k.app; st.pe_stats[4 * N + e] += k.drop; }
+    uint32_t* ring = st.ring + (((int64_t)e * c.D + sender) << 7);
+    uint32_t head = hl & 0xffu, len = hl >> 8, dropped = 0u;
+    if (len == (uint32_t)GW_QUEUE_CAP) {                  // deque(maxlen=100): drop the oldest
+        head = (head + 1u) & GW_RING_MASK;
+        len--;
+        dropped = 1u;
+    }
+    ring[(head + len) & GW_RING_MASK] = (uint32_t)(c.mac_hdr + c.net_hdr + pb);
+    len++;
+    st.qhl[(int64_t)sender * N + e] = (uint16_t)(head | (len << 8));
+    if (st.pe_stats) { st.pe_stats[2 * N + e] += 1u; st.pe_stats[4 * N + e] += dropped; }
 }
 
 // counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound

@@ -194,6 +194,7 @@ int gw_fill_dev_const(const gw_config& cfg, const GwHostTables& tab, GwDevConst&
     k.mac_hdr = cfg.mac_header_bytes; k.net_hdr = cfg.net_header_bytes;
     k.duration_factor = cfg.duration_factor; k.max_duration = cfg.max_duration;
     for (int i = 0; i < D; ++i) { k.mult[i] = cfg.mult[i]; k.inv16[i] = cfg.mult[i] > 0 ? (65536u + (uint32_t)cfg.mult[i] - 1u) / (uint32_t)cfg.mult[i] : 0u; }
+    for (int i = 0; i < D; ++i) k.inv20[i] = cfg.mult[i] > 0 ? ((1u << 20) + (uint32_t)cfg.mult[i] - 1u) / (uint32_t)cfg.mult[i] : 0u;
     k.start_time = cfg.start_time;
     k.no_traffic = (cfg.flags & GW_CFG_NO_COUNTER_TRAFFIC) ? 1 : 0;
     k.peer_receive = (cfg.flags & GW_CFG_PEER_RECEIVE) ? 1 : 0;

@@ -32,6 +32,7 @@ struct GwDevConst {
     double  tie_filter;                 // a tick can only fall exactly on t when (t - wake)/interval is this close to an integer
     int32_t no_traffic, peer_receive, float_duration;   // GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION
     int32_t dest[GW_MAX_DEVICES];
+    uint32_t inv20[GW_MAX_DEVICES];     // ceil(2^20 / mult[i]): p / mult for p * mult < 2^20 (generic kernel's append index -> tick)
 };
 
 struct GwBp { uint32_t t0, c0; };        // counting restarts at tick t0 with counter value c0

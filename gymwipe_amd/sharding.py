@@ -82,9 +82,10 @@ class PipelinedGather:
 class ObservationGather:
     """All-gather of equally sized StepRecords over the default process group."""
 
-    def __init__(self, record, world_size=None):
-        import torch.distributed as dist
-        self._dist = dist
+    def __init__(self, record, world_size=None, dist_module=None):
+        if dist_module is None:                      # tests may inject a loop-back stand-in for the process group
+            import torch.distributed as dist_module
+        dist = self._dist = dist_module
         self.world = world_size if world_size is not None else dist.get_world_size()
         self.record = record
         self.out = torch.empty(self.world * record.nbytes, dtype=torch.uint8, device=record.buf.device)
@@ -122,9 +123,10 @@ class ChunkedFeedbackGather:
     `env.pack_feedback` / `env.unpack_feedback` (the HIP kernels behind the C-ABI).
     """
 
-    def __init__(self, num_envs, device, pack, world_size=None, chunk=64, depth=2):
-        import torch.distributed as dist
-        self._dist = dist
+    def __init__(self, num_envs, device, pack, world_size=None, chunk=64, depth=2, dist_module=None):
+        if dist_module is None:                      # tests may inject a loop-back stand-in for the process group
+            import torch.distributed as dist_module
+        dist = self._dist = dist_module
         self.world = world_size if world_size is not None else dist.get_world_size()
         n, g = int(num_envs), int(chunk)
         self.num_envs, self.chunk, self.depth = n, g, depth

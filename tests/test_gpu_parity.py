@@ -136,6 +136,33 @@ def test_event_totals_match_oracle(explicit):
     assert st["dropped"] == int(orc.get("n_dropped").sum())
 
 
+@pytest.mark.parametrize("D,mult", [(32, None), (4, [100, 37, 1, 64]), (3, [16, 99, 7])])
+def test_generic_kernel_heavy_appends_totals_and_queues(D, mult):
+    """Explicit-ring kernel with the most appends a step can make: every duration 19 (20 ticks per step) at D = 32,
+    and multiplicities up to the deque's capacity (every tick replaces the whole queue).  gw_stats_read's wave-level
+    totals -- 64 lanes x 20 ticks x mult does not fit 16 bits -- and the queue contents against the oracle."""
+    import torch
+    N, K = 2048, 24
+    env, orc = _mk(N, D, explicit=True, multiplicity=mult)
+    rng = np.random.default_rng(5)
+    env.reset(); orc.reset()
+    for k in range(K):
+        dev = rng.integers(0, D, N, dtype=np.int32)
+        dur = np.full(N, 19, np.int32) if k % 3 else rng.integers(0, 20, N, dtype=np.int32)
+        o, r, d, _ = env.step({"device": torch.from_numpy(dev), "duration": torch.from_numpy(dur)})
+        oo, orr, od = orc.step(dev, dur)
+        assert (o.cpu().numpy() == oo).all() and (r.cpu().numpy() == orr).all(), k
+        if k in (3, 11):
+            env.reset(); orc.reset()
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="heavy appends")
+    st = env.stats()
+    assert st["steps"] == K * N
+    for name, field in (("transmissions", "n_tx"), ("delivered", "n_delivered"), ("appended", "n_appended"),
+                        ("popped", "n_popped"), ("dropped", "n_dropped")):
+        assert st[name] == int(orc.get(field).sum()), name
+    assert st["appended"] > 64 * 65535 // 64 * 4                      # far past what a 16-bit field per wave could hold
+
+
 def test_invalid_action_is_flagged_and_env_left_untouched():
     import torch
     from gymwipe_amd import _native as nat

@@ -30,7 +30,7 @@ EXPORTS = (
     "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue",
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
-    "gw_plant_state_ptr", "gw_plant_get_state", "gw_plant_feedback", "gw_plant_update_feedback", "gw_now_ptr",
+    "gw_plant_state_ptr", "gw_plant_get_state", "gw_plant_feedback", "gw_plant_update_feedback", "gw_now_ptr", "gw_pendulum_step",
     "gw_ctrl_config_default", "gw_ctrl_create", "gw_ctrl_destroy", "gw_ctrl_step", "gw_ctrl_get_state",
     "gw_grid_config_default", "gw_grid_create", "gw_grid_destroy", "gw_grid_run", "gw_grid_get_state", "gw_grid_set_position",
 )
@@ -192,6 +192,7 @@ def lib():
     L.gw_ctrl_get_state.argtypes, L.gw_ctrl_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     L.gw_plant_update_feedback.argtypes, L.gw_plant_update_feedback.restype = [vp, vp, C.c_int64, vp, vp, vp, vp], C.c_int
     L.gw_now_ptr.argtypes, L.gw_now_ptr.restype = [vp, C.POINTER(vp), C.POINTER(i64)], C.c_int
+    L.gw_pendulum_step.argtypes, L.gw_pendulum_step.restype = [vp, vp, vp, vp, vp, vp, vp, vp], C.c_int
     L.gw_grid_config_default.argtypes, L.gw_grid_config_default.restype = [C.POINTER(GridConfig), i64, i32], C.c_int
     L.gw_grid_create.argtypes, L.gw_grid_create.restype = [C.POINTER(GridConfig), vp, C.POINTER(vp)], C.c_int
     L.gw_grid_destroy.argtypes, L.gw_grid_destroy.restype = [vp], C.c_int

@@ -67,6 +67,16 @@ __device__ __forceinline__ bool receive(const StepMath& m, double ber, const TxT
     return m.decodes(err, pay_bits);
 }
 
+// Decode outcome of one reception: certain by class (gw_tables.cpp: decode_class), or the exact arithmetic
+__device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls_valid, double ber, const TxTimes& x,
+                                       double br, double hdr_bits, double pay_bits, uint32_t& fl)
+{
+    if (!(x.t_e >= x.stop)) fl |= GW_FLAG_REFEXC;        // `not t.completed` -> KeyError in the reference
+    if (cls_valid && cls != GW_CLS_COMPUTE) return cls == GW_CLS_OK;
+    uint32_t dummy = 0;
+    return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
+}
+
 __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value)), v >= 0
 {
     return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) +

@@ -35,14 +35,6 @@ __device__ __forceinline__ uint32_t word_of(const uint4& w, int i)
     return i == 0 ? w.x : (i == 1 ? w.y : (i == 2 ? w.z : w.w));
 }
 
-__device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls_valid, double ber, const TxTimes& x,
-                                       double br, double hdr_bits, double pay_bits, uint32_t& fl)
-{
-    if (!(x.t_e >= x.stop)) fl |= GW_FLAG_REFEXC;
-    if (cls_valid && cls != GW_CLS_COMPUTE) return cls == GW_CLS_OK;
-    uint32_t dummy = 0;
-    return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
-}
 
 // The rollout kernel wants each env's actions and feedback contiguous ([N][Kp]: one 16-byte load = 8 steps of
 // actions, one dword store = 4 steps of feedback); the C-ABI takes and returns step-major arrays ([K][N]).  Both

@@ -67,11 +67,18 @@ __device__ __forceinline__ uint32_t ring_head_size(const Ring& r, uint32_t inv20
 }
 
 // write this step's appends: entry p (0-based) sits in slot (tail0 + p) & mask and holds base + min(ctr0 + p / mult, bound).
-// Aligned groups of four go out as one 16-byte store (the ring is 128 entries, so a group never wraps).
+// Only whole aligned groups of four are stored (the ring is 128 entries, so a group never wraps): the first group keeps
+// the older entries in front of the tail from `head_group`, the copy of it loaded at the start of the step; the last
+// group runs past the new tail with values nothing reads before a later append overwrites them (a full deque still
+// leaves 28 free slots).
 __device__ __forceinline__ void ring_flush(uint32_t* ring, uint32_t tail0, uint32_t app, uint32_t mult, uint32_t inv20,
-                                           uint32_t ctr0, uint32_t bound, uint32_t base_bytes)
+                                           uint32_t ctr0, uint32_t bound, uint32_t base_bytes, uint4 head_group)
 {
-    uint32_t p = app > (uint32_t)GW_RING_PHYS ? app - (uint32_t)GW_RING_PHYS : 0u;   // older ones would be overwritten anyway
+    if (app == 0u) return;
+    // more appends than the ring holds (multiplicity > 6): only the last <= 124 can still be live (the deque keeps 100);
+    // start at a group boundary so that the stores cover less than one lap of the ring
+    uint32_t p = 0u;
+    if (app > 124u) { p = app - 124u; p += (4u - ((tail0 + p) & 3u)) & 3u; }
     uint32_t t = (p * inv20) >> 20;                       // p / mult
     uint32_t rem = mult - (p - t * mult);                 // copies of tick t still to write
     uint32_t slot = (tail0 + p) & GW_RING_MASK;
@@ -81,22 +88,29 @@ __device__ __forceinline__ void ring_flush(uint32_t* ring, uint32_t tail0, uint3
         if (--rem == 0u) { ++t; rem = mult; }
         return out;
     };
+    const uint32_t lead = slot & 3u;                      // older entries in front of the first append, in its group
+    if (lead != 0u) {
+        uint4 v = head_group;
+        if (lead <= 1u) v.y = next();
+        if (lead <= 2u) v.z = next();
+        v.w = next();
+        *reinterpret_cast<uint4*>(ring + (slot & ~3u)) = v;
+        const uint32_t wrote = 4u - lead;
+        p += wrote;
+        slot = (slot + wrote) & GW_RING_MASK;
+    }
     while (p < app) {
-        if ((slot & 3u) == 0u && app - p >= 4u) {
-            uint4 v;
-            v.x = next(); v.y = next(); v.z = next(); v.w = next();
-            *reinterpret_cast<uint4*>(ring + slot) = v;
-            p += 4u;
-            slot = (slot + 4u) & GW_RING_MASK;
-        } else {
-            ring[slot] = next();
-            p += 1u;
-            slot = (slot + 1u) & GW_RING_MASK;
-        }
+        uint4 v;
+        v.x = next(); v.y = next(); v.z = next(); v.w = next();
+        *reinterpret_cast<uint4*>(ring + slot) = v;
+        p += 4u;
+        slot = (slot + 4u) & GW_RING_MASK;
     }
 }
 
-template <bool PER_ENV_STATS>
+// DT > 0: compile-time sender count -- queue heads/lengths and the 16-byte ring group at every sender's tail are loaded up
+// front into registers (their latency overlaps everything else); DT == 0: any sender count, loaded where needed.
+template <int DT, bool PER_ENV_STATS>
 __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                                                         const int32_t* __restrict__ device,
                                                         const int32_t* __restrict__ duration,
@@ -107,10 +121,40 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
     const int64_t N = st.N;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const GwDevConst& c = *st.cst;
-    const int D = c.D, R = c.R, S = c.S, RRM = c.D;
+    const int D = DT > 0 ? DT : c.D;
+    const int R = D + 1, S = GW_MAX_NSTATES, RRM = D;
+
+    // the step tables the walk looks up per transmission (GwBlobLayout, built by gw_create) -> LDS: the window loop's
+    // state -> BER chain is two dependent lookups per data packet, an L2 round trip each when read from global memory
+    constexpr int DM = DT > 0 ? DT : GW_MAX_DEVICES;
+    constexpr GwBlobLayout LM(DM);
+    const GwBlobLayout L(D);
+    __shared__ __attribute__((aligned(16))) uint8_t s_blob[LM.lds_total];
+    for (int i = threadIdx.x; i < (L.lds_total >> 4); i += blockDim.x)
+        *reinterpret_cast<uint4*>(s_blob + ((uint32_t)i << 4)) = *reinterpret_cast<const uint4*>(st.blob + ((uint32_t)i << 4));
+    const double* s_ber = reinterpret_cast<const double*>(s_blob + L.ber);   // [0][d][s] d hears the RRM; [1][d][s] the RRM hears d
+    const uint8_t* s_h1 = s_blob + L.h1;                                       // state of j after the announcement
+    const uint8_t* s_rr = s_blob + L.r1;                                       // state of the RRM after a packet of d
+    const uint8_t* g_h2 = st.blob + L.h2;                                      // j after the announcement and >= 1 packet of d (idem)
+    const uint8_t* s_cls = s_blob + L.cls;
 
     Tally k = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
+
+    // per-sender queue words and tail groups, issued before anything depends on them
+    constexpr int DR = DT > 0 ? DT : 1;
+    uint32_t hlv[DR];
+    uint4 hg[DR];
+    if (DT > 0 && e < N) {
+#pragma unroll
+        for (int i = 0; i < DR; ++i) hlv[i] = st.qhl[(int64_t)i * N + e];
+#pragma unroll
+        for (int i = 0; i < DR; ++i) {
+            const uint32_t tail = ((hlv[i] & 0xffu) + (hlv[i] >> 8)) & GW_RING_MASK;
+            hg[i] = *reinterpret_cast<const uint4*>(st.ring + ((((int64_t)e * D + i) << 7) + (tail & ~3u)));
+        }
+    }
+    __syncthreads();
 
     if (e < N) {
         const int d = device[e];
@@ -146,20 +190,29 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
             // ---- A.1 / A.2: announcement ---------------------------------------------
-            const int L = ndigits(slots) + (c.float_duration ? 2 : 0);   // len(str(10000.0)) == len("10000") + 2
-            const double pd_a = m.over_rate((double)(L * 8));
+            const int La = ndigits(slots) + (c.float_duration ? 2 : 0);  // len(str(10000.0)) == len("10000") + 2
+            const double pd_a = m.over_rate((double)(La * 8));
             const TxTimes an = tx_times(m, t_a, hd, pd_a);
             k.tx++;
-            uint8_t s_d = st.rxs[(int64_t)d * N + e];
-            const uint8_t s_d_old = s_d;
-            s_d = st.trans[((int64_t)d * R + RRM) * S + s_d];
-            const double ber_a = st.ber[((int64_t)d * R + RRM) * S + s_d];
-            const bool granted = receive(m, ber_a, an, br, hdr_bits, (double)(L * 8) * c.coded_factor, fl);
+            const uint8_t s_d_old = st.rxs[(int64_t)d * N + e];
+            const uint8_t s_d = s_h1[d * S + s_d_old];
+            const double ber_a = s_ber[d * S + s_d];
+            const bool cls_valid = t_a < c.cls_limit;
+            const bool idem = c.idem_states != 0;
+            const bool granted = decode(m, s_cls[d * S + s_d], cls_valid, ber_a, an, br, hdr_bits,
+                                        (double)(La * 8) * c.coded_factor, fl);
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
             // ---- A.3: window at sender d -----------------------------------------------
-            const uint16_t hl_d = st.qhl[(int64_t)d * N + e];
+            uint32_t hl_d = 0u;
+            uint4 hg_d = make_uint4(0u, 0u, 0u, 0u);
+            if (DT > 0) {
+#pragma unroll
+                for (int i = 0; i < DR; ++i) { if (i == d) { hl_d = hlv[i]; hg_d = hg[i]; } }
+            } else {
+                hl_d = st.qhl[(int64_t)d * N + e];
+            }
             Ring rd;
             rd.base = st.ring + (((int64_t)e * D + d) << 7);
             rd.head = hl_d & 0xffu;
@@ -170,9 +223,11 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const uint32_t inv20_d = c.inv20[d];
             int n_data = 0;
             uint32_t n_ticks = 0;                                         // counter ticks inside this step
-            uint8_t s_r = 0;
-            bool s_r_loaded = false;
-            uint8_t s_r_old = 0;
+            const uint8_t s_r_old = st.rxs[(int64_t)RRM * N + e];
+            uint8_t s_r = s_r_old;
+            const uint8_t s_r1 = s_rr[d * S + s_r_old];                    // the RRM after one packet of d
+            const double ber_x1 = s_ber[(D + d) * S + s_r1];
+            const uint32_t cls_x1 = s_cls[(D + d) * S + s_r1];
             // receive-mode MAC at the destination (simple_stack.py:443-448): it is idle during d's window (its own
             // window, the only thing that blocks its phyIn handler, ended a slot before the previous step did)
             const int j_peer = (c.peer_receive && c.dest[d] != d) ? c.dest[d] : -1;
@@ -229,10 +284,16 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
                     k.tx++;
                     n_data++;
-                    if (!s_r_loaded) { s_r = st.rxs[(int64_t)RRM * N + e]; s_r_old = s_r; s_r_loaded = true; }
-                    s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
-                    const double ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
-                    const bool ok = receive(m, ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl);
+                    double ber_x = ber_x1;
+                    uint32_t cls_x = cls_x1;
+                    if (idem) {
+                        s_r = s_r1;
+                    } else {                                              // not seen with f64 link powers; full tables in HBM
+                        s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
+                        ber_x = st.ber[((int64_t)RRM * R + d) * S + s_r];
+                        cls_x = st.cls[((int64_t)RRM * R + d) * S + s_r];
+                    }
+                    const bool ok = decode(m, cls_x, cls_valid, ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl);
                     if (ok) {                                             // devices.py:163-168, counter_traffic.py:75-80
                         k.deliv++;
                         rvm |= (1u << d);
@@ -267,11 +328,13 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 }
             }
             st.qhl[(int64_t)d * N + e] = (uint16_t)(rd.head | (rd.len << 8));
-            ring_flush(rd.base, tail0_d, rd.app, mult_d, inv20_d, ctr0, bound, base_bytes);
-            for (int i = 0; i < D; ++i) {
+            if (DT == 0 && rd.app != 0u && (tail0_d & 3u) != 0u) hg_d = *reinterpret_cast<const uint4*>(rd.base + (tail0_d & ~3u));
+            ring_flush(rd.base, tail0_d, rd.app, mult_d, inv20_d, ctr0, bound, base_bytes, hg_d);
+#pragma unroll
+            for (int i = 0; i < (DT > 0 ? DT : D); ++i) {
                 if (i == d) continue;
                 // the same n_ticks ticks d's walk just counted (all senders tick together)
-                const uint16_t hl = st.qhl[(int64_t)i * N + e];
+                const uint32_t hl = DT > 0 ? hlv[DT > 0 ? i : 0] : (uint32_t)st.qhl[(int64_t)i * N + e];
                 Ring ri;
                 ri.base = st.ring + (((int64_t)e * D + i) << 7);
                 ri.head = hl & 0xffu;
@@ -282,7 +345,9 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 if (n_ticks != 0u && mult_i != 0u) {
                     ring_ticks(ri, n_ticks, mult_i, k);
                     st.qhl[(int64_t)i * N + e] = (uint16_t)(ri.head | (ri.len << 8));
-                    ring_flush(ri.base, tail0, ri.app, mult_i, c.inv20[i], ctr0, bound, base_bytes);
+                    uint4 hgi = DT > 0 ? hg[DT > 0 ? i : 0] : make_uint4(0u, 0u, 0u, 0u);
+                    if (DT == 0 && (tail0 & 3u) != 0u) hgi = *reinterpret_cast<const uint4*>(ri.base + (tail0 & ~3u));
+                    ring_flush(ri.base, tail0, ri.app, mult_i, c.inv20[i], ctr0, bound, base_bytes, hgi);
                 }
             }
             uint32_t ctr_new = ctr0 + n_ticks;                            // `if counter < bound: counter += 1` per tick
@@ -290,20 +355,20 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
 
             // ---- rx-power state of every radio (simple_stack.py:130-157) ---------------------
             if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
-            if (s_r_loaded && s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
+            if (s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
             if (j_peer >= 0) {
                 if (s_p != s_p_old) st.rxs[(int64_t)j_peer * N + e] = s_p;
                 if (n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
             }
             for (int j = 0; j < D; ++j) {
                 if (j == d || j == j_peer) continue;
-                uint8_t s = st.rxs[(int64_t)j * N + e];
-                const uint8_t s0 = s;
-                s = st.trans[((int64_t)j * R + RRM) * S + s];
-                for (int n = 0; n < n_data; ++n) {
-                    const uint8_t s2 = st.trans[((int64_t)j * R + d) * S + s];
-                    if (s2 == s) break;                                   // fixed point: g(g(a,p),p) == g(a,p)
-                    s = s2;
+                const uint8_t s0 = st.rxs[(int64_t)j * N + e];
+                uint8_t s;
+                if (idem) {
+                    s = n_data ? g_h2[(j * D + d) * S + s0] : s_h1[j * S + s0];
+                } else {
+                    s = st.trans[((int64_t)j * R + RRM) * S + s0];
+                    for (int n = 0; n < n_data; ++n) s = st.trans[((int64_t)j * R + d) * S + s];
                 }
                 if (s != s0) st.rxs[(int64_t)j * N + e] = s;
             }
@@ -436,12 +501,24 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
 {
     const unsigned blk = (unsigned)st.block;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
-    if (st.pe_stats)
-        hipLaunchKernelGGL(ct_step_kernel<true>, dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, device, duration, obs, reward, done);
-    else
-        hipLaunchKernelGGL(ct_step_kernel<false>, dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, device, duration, obs, reward, done);
+#define GW_LAUNCH_GENERIC(DT_)                                                                                   \
+    do {                                                                                                        \
+        if (st.pe_stats)                                                                                        \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,      \
+                               st, device, duration, obs, reward, done);                                        \
+        else                                                                                                    \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,     \
+                               st, device, duration, obs, reward, done);                                        \
+    } while (0)
+    switch (st.D) {
+    case 2:  GW_LAUNCH_GENERIC(2); break;
+    case 3:  GW_LAUNCH_GENERIC(3); break;
+    case 4:  GW_LAUNCH_GENERIC(4); break;
+    case 8:  GW_LAUNCH_GENERIC(8); break;
+    case 16: GW_LAUNCH_GENERIC(16); break;
+    default: GW_LAUNCH_GENERIC(0); break;
+    }
+#undef GW_LAUNCH_GENERIC
     return check_launch();
 }
 

@@ -66,15 +66,6 @@ __device__ __forceinline__ uint32_t word_of(const uint4& w, int i)          // i
     return i == 0 ? w.x : (i == 1 ? w.y : (i == 2 ? w.z : w.w));
 }
 
-// Decode outcome of one reception: certain by class, or the exact arithmetic (ct_common.hip.h)
-__device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls_valid, double ber, const TxTimes& x,
-                                       double br, double hdr_bits, double pay_bits, uint32_t& fl)
-{
-    if (!(x.t_e >= x.stop)) fl |= GW_FLAG_REFEXC;        // `not t.completed` -> KeyError in the reference
-    if (cls_valid && cls != GW_CLS_COMPUTE) return cls == GW_CLS_OK;
-    uint32_t dummy = 0;
-    return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
-}
 
 // Step tables ("blob", built by the host at gw_create: gw_api.cpp; byte offsets all multiples of 16).
 // Staged in LDS, because the step's first decisions wait on two dependent lookups in them:
@@ -95,13 +86,16 @@ __device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls
 
 // DT > 0: compile-time device count, the qb byte record is held in registers (NWC 16-byte words);
 // DT == 0: any device count, the record's bytes are read and written in memory.
-template <int DT>
-__global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
-                                                         const int32_t* __restrict__ device,
-                                                         const int32_t* __restrict__ duration,
-                                                         int32_t* __restrict__ obs,
-                                                         float* __restrict__ reward,
-                                                         uint8_t* __restrict__ done)
+// FEEDBACK: write the CounterTraffic interpreter's (obs, reward, done); the fused pendulum step (below) replaces them by
+// the plant's.  now_out: the env's clock after the step (unchanged for a bad action), live_out: e < N.
+template <int DT, bool FEEDBACK>
+__device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevConst& c,
+                                                 const int32_t* __restrict__ device,
+                                                 const int32_t* __restrict__ duration,
+                                                 int32_t* __restrict__ obs,
+                                                 float* __restrict__ reward,
+                                                 uint8_t* __restrict__ done,
+                                                 double& now_out, bool& live_out)
 {
     constexpr bool PACKED = DT > 0;                      // the byte record is held in registers
     constexpr int NWC = DT > 0 ? (2 * DT + 1 + 15) / 16 : 1;   // 16-byte words of the record
@@ -158,6 +152,8 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
     for (int w = 0; w < NWC; ++w) qw[w] = PACKED ? ld<uint4>(st.qb, oql + 16u * w) : make_uint4(0u, 0u, 0u, 0u);
     uint4 sa0 = ld<uint4>(st.sa, o32l);
     uint4 sa1 = ld<uint4>(st.sa, o32l + 16u);
+    now_out = tw.x;
+    live_out = live;
 
     // ---- constants -> registers, under the shadow of the loads above --------------------------------
     StepMath m(c);
@@ -211,9 +207,11 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             fl = GW_FLAG_BADACT;
             k_bad = 1;
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
-            obs[e] = latest + cbound;
-            reward[e] = 0.0f;
-            done[e] = (uint8_t)dn;
+            if (FEEDBACK) {
+                obs[e] = latest + cbound;
+                reward[e] = 0.0f;
+                done[e] = (uint8_t)dn;
+            }
         } else {
             k_steps = 1;
             const uint32_t bound = (uint32_t)cbound;
@@ -443,9 +441,12 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
             int32_t r = last_abs - abs_d;
             last_abs = abs_d;
             r = r > 10 ? 10 : (r < -10 ? -10 : r);
-            obs[e] = latest + cbound;
-            reward[e] = (float)r;
-            done[e] = (uint8_t)dn;
+            if (FEEDBACK) {
+                obs[e] = latest + cbound;
+                reward[e] = (float)r;
+                done[e] = (uint8_t)dn;
+            }
+            now_out = t_end;
 
             st_(st.tw, o16, make_double2(t_end, wake));
             st_(st.tk, o16, tau);                                         // only the tick counter changes
@@ -459,6 +460,94 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
         st_(st.sa, o32 + 16u, sa1);
     }
     STAMP(12);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
+                                                         const int32_t* __restrict__ device,
+                                                         const int32_t* __restrict__ duration,
+                                                         int32_t* __restrict__ obs,
+                                                         float* __restrict__ reward,
+                                                         uint8_t* __restrict__ done)
+{
+    double now_new;
+    bool live;
+    ct_step_sfx_body<DT, true>(st, c, device, duration, obs, reward, done, now_new, live);
+}
+
+// ---- BASELINE config 4: env.step() of the pendulum env in ONE launch ------------------------------------------------
+// = the band-assignment step of the env's network (sensor + silent controller, D = 2) + OdePlant.updateState to the
+// env's new clock (plants/core.py:38-49; builder-defined linear plant x <- A x + B u on the f64 matrix cores, see
+// plant_mfma.hip for the operand mapping) + InvertedPendulumInterpreter's reading of the plant
+// (envs/inverted_pendulum.py:27-57).  The step kernel is thread-per-env, the MFMA tile is 16 envs x 4 state
+// components: the wave's 64 plant states go through an LDS transpose and four rounds of 16 envs each.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c, GwPlantDev p,
+                                                       const int32_t* __restrict__ device,
+                                                       const int32_t* __restrict__ duration,
+                                                       int32_t* __restrict__ obs, float* __restrict__ reward,
+                                                       double* __restrict__ angle_deg)
+{
+    __shared__ double s_x[64][5];                        // [env of the wave][component], padded: conflict-free both ways
+    const int lane = threadIdx.x;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    const bool mine = e < p.N;
+    const int64_t el = mine ? e : 0;
+    // the plant's state, loaded before the step so that its latency hides behind the network walk
+    const double2 x01 = *reinterpret_cast<const double2*>(p.x + el * 4);
+    const double2 x23 = *reinterpret_cast<const double2*>(p.x + el * 4 + 2);
+    const double u = p.u[el];
+    const double tl = p.t_last[el];
+
+    double now_new;
+    bool live;
+    ct_step_sfx_body<2, false>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
+
+    // substeps to take: n = round((now - last) / dt), nothing if time did not advance
+    int n = 0;
+    if (mine && live && now_new > tl) n = (int)llrint((now_new - tl) * p.inv_dt);
+    s_x[lane][0] = x01.x; s_x[lane][1] = x01.y; s_x[lane][2] = x23.x; s_x[lane][3] = x23.y;
+    __syncthreads();
+    const int g = lane >> 4, col = lane & 15;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {                        // 16 envs of the wave per round
+        const int src = 16 * q + col;
+        double xg = s_x[src][g];
+        const double uq = __shfl(u, src);
+        const double ug = (g == 0) ? uq : 0.0;           // B operand of the input MFMA: row 0 = u
+        int nq = __shfl(n, src);
+        while (__any(nq > 0)) {
+            const int chunk = nq > GW_PLANT_KMAX ? GW_PLANT_KMAX : nq;     // this round's substeps (0 = done)
+            double xn = xg;
+            for (int grp = 0; grp < GW_PLANT_KMAX / 4 && __any(chunk > 4 * grp); ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
+                const double a_p = p.Pop[grp * 64 + lane];
+                const double a_q = p.Qop[grp * 64 + lane];
+                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_q, ug, acc, 0, 0, 0);
+                const int r = chunk - (4 * grp + 1);                 // which candidate is mine (if any)
+                if (r >= 0 && r < 4) xn = r == 0 ? acc.x : (r == 1 ? acc.y : (r == 2 ? acc.z : acc.w));
+            }
+            xg = xn;
+            nq -= chunk;
+        }
+        s_x[src][g] = xg;
+    }
+    __syncthreads();
+    if (mine) {
+        const double a0 = s_x[lane][0], a1 = s_x[lane][1], a2 = s_x[lane][2], a3 = s_x[lane][3];
+        if (n > 0) {
+            *reinterpret_cast<double2*>(p.x + e * 4) = make_double2(a0, a1);
+            *reinterpret_cast<double2*>(p.x + e * 4 + 2) = make_double2(a2, a3);
+            p.t_last[e] = now_new;
+            p.nsub[e] += (unsigned long long)n;
+        }
+        const double deg = a2 * (180.0 / 3.141592653589793);        // envs/inverted_pendulum.py:27-57
+        if (obs) obs[e] = (int32_t)deg;
+        if (reward) reward[e] = (float)fabs(180.0 - deg);
+        if (angle_deg) angle_deg[e] = deg;
+    }
 }
 
 // fresh env: counters 1 (counter_traffic.py:48) == breakpoint (tick 0, value 1); first tick at t = 0;
@@ -580,5 +669,13 @@ int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream)
     const int64_t total = st.N * (int64_t)st.D;
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(ct_received_sfx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, st, out);
+    return ok_or_ehip();
+}
+
+int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantDev& p, const int32_t* device, const int32_t* duration,
+                        int32_t* obs, float* reward, double* angle_deg, void* stream)
+{
+    const unsigned grid = (unsigned)((st.N + 63) / 64);
+    hipLaunchKernelGGL(pend_step_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
     return ok_or_ehip();
 }

@@ -224,6 +224,14 @@ int gw_fill_dev_const(const gw_config& cfg, const GwHostTables& tab, GwDevConst&
 
 int gw_validate_config(const gw_config& cfg) { return validate(cfg); }
 
+// for the entry points that drive a gw_env together with another handle (gw_plant_api.cpp: gw_pendulum_step)
+int gw_env_internals(gw_env* env, const GwState** st, const GwDevConst** cst, int* hip_device)
+{
+    if (!env) return fail(GW_EINVAL, "env is NULL");
+    *st = &env->st; *cst = &env->cst_host; *hip_device = env->cfg.hip_device;
+    return GW_OK;
+}
+
 extern "C" {
 
 int gw_abi_version(void) { return GW_ABI_VERSION; }

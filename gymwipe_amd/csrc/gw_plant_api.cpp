@@ -17,6 +17,9 @@ int gw_plant_launch_init(const GwPlantDev& p, const double* x0, double u0, void*
 int gw_plant_launch_feedback(const GwPlantDev& p, int32_t* obs, float* reward, double* angle_deg, void* stream);
 
 int gw_set_error(int code, const char* fmt, ...);      // gw_api.cpp
+int gw_env_internals(gw_env* env, const GwState** st, const GwDevConst** cst, int* hip_device);   // gw_api.cpp
+int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantDev& p, const int32_t* device, const int32_t* duration,
+                        int32_t* obs, float* reward, double* angle_deg, void* stream);             // ct_step_sfx.hip
 
 struct gw_plant {
     gw_plant_config cfg;
@@ -158,6 +161,23 @@ int gw_plant_update_feedback(gw_plant* p, const void* now_dev, int64_t stride_by
     PLANT_HIP(hipSetDevice(p->cfg.hip_device), (void)0);
     if (gw_plant_launch_update(p->dev, now_dev, stride_bytes, obs_dev, reward_dev, angle_deg_dev, stream))
         return gw_set_error(GW_EHIP, "plant update launch failed");
+    return GW_OK;
+}
+
+int gw_pendulum_step(gw_env* env, gw_plant* p, const int32_t* device_dev, const int32_t* duration_dev, int32_t* obs_dev,
+                     float* reward_dev, double* angle_deg_dev, void* stream)
+{
+    if (!env || !p) return gw_set_error(GW_EINVAL, "env/plant is NULL");
+    if (!device_dev || !duration_dev) return gw_set_error(GW_EINVAL, "gw_pendulum_step: NULL action pointer");
+    const GwState* st = nullptr; const GwDevConst* cst = nullptr; int dev = 0;
+    int rc = gw_env_internals(env, &st, &cst, &dev);
+    if (rc) return rc;
+    if (!st->tk) return gw_set_error(GW_EUNSUPPORTED, "gw_pendulum_step needs the default (suffix) queue mode");
+    if (st->D != 2) return gw_set_error(GW_EUNSUPPORTED, "gw_pendulum_step: the env's network has two assignable devices (sensor, controller)");
+    if (st->N != p->dev.N || dev != p->cfg.hip_device) return gw_set_error(GW_EINVAL, "env and plant differ in num_envs or hip_device");
+    PLANT_HIP(hipSetDevice(dev), (void)0);
+    if (gw_launch_pend_step(*st, *cst, p->dev, device_dev, duration_dev, obs_dev, reward_dev, angle_deg_dev, stream))
+        return gw_set_error(GW_EHIP, "pendulum step launch failed");
     return GW_OK;
 }
 

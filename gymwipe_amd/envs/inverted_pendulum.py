@@ -69,14 +69,28 @@ class VecInvertedPendulumEnv(BaseEnv):
         """envs/inverted_pendulum.py:95-99: returns an observation, resets nothing."""
         return self._feedback()[0]
 
-    def step(self, action):
-        """:101-113 for every env: assign the band, run to the end of the assignment, read the plant."""
+    def step(self, action, fused=True):
+        """:101-113 for every env: assign the band, run to the end of the assignment, read the plant -- ONE kernel launch
+        (``gw_pendulum_step``: band-assignment step + plant advance on the matrix cores + interpreter feedback).
+        ``fused=False`` issues the same work as two launches (``gw_step`` + ``gw_plant_update_feedback``); results are identical."""
         torch = self._torch
-        self.network.step(action)
-        with torch.cuda.device(self.device):               # OdePlant.updateState to the new env clock + the interpreter's
-            nat.check(self.plant._L.gw_plant_update_feedback(    # reading of the plant, one launch
-                self.plant._h, self._now[0], self._now[1], self._obs.data_ptr(), self._rew.data_ptr(),
-                self._angle.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+        net = self.network
+        if not fused:
+            net.step(action)
+            with torch.cuda.device(self.device):           # OdePlant.updateState to the new env clock + the interpreter's
+                nat.check(self.plant._L.gw_plant_update_feedback(    # reading of the plant
+                    self.plant._h, self._now[0], self._now[1], self._obs.data_ptr(), self._rew.data_ptr(),
+                    self._angle.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
+            return self._obs, self._rew, self._done, {"Sensor angle": self._angle}
+        dev, dur = action["device"], action["duration"]
+        if not net._ready(dev):
+            dev = net._as_i32(dev, "device")
+        if not net._ready(dur):
+            dur = net._as_i32(dur, "duration")
+        with torch.cuda.device(self.device):
+            nat.check(net._L.gw_pendulum_step(net._h, self.plant._h, dev.data_ptr(), dur.data_ptr(), self._obs.data_ptr(),
+                                              self._rew.data_ptr(), self._angle.data_ptr(),
+                                              torch.cuda.current_stream(self.device).cuda_stream))
         return self._obs, self._rew, self._done, {"Sensor angle": self._angle}
 
     def render(self, mode="human", close=False):           # :115-116

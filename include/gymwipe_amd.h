@@ -34,6 +34,7 @@
  *   gw_enqueue         SimpleNetworkDevice.send -> SimpleMac queue           networking/devices.py:84-86, simple_stack.py:463-471
  *   gw_rollout         a Python loop over step()
  *   gw_pack_feedback / gw_unpack_feedback   (multi-GPU exchange format; the reference is single-process)
+ *   gw_pendulum_step   InvertedPendulumEnv.step              envs/inverted_pendulum.py:101-113
  *   gw_plant_*         OdePlant.updateState, SlidingPendulum getters / setMotorVelocity   plants/core.py:38-49,
  *                      plants/sliding_pendulum.py:57-85   (builder-defined linear plant)
  *   gw_grid_*          SimMan.runSimulation(seconds) over the benchmark fixture, Position.set
@@ -238,6 +239,11 @@ int gw_plant_feedback(gw_plant* p, int32_t* obs_dev, float* reward_dev, double* 
 /* gw_plant_update and gw_plant_feedback in one launch (what an env.step() of the pendulum env needs after the network step) */
 int gw_plant_update_feedback(gw_plant* p, const void* now_dev, int64_t stride_bytes, int32_t* obs_dev, float* reward_dev,
                              double* angle_deg_dev, void* stream);
+/* env.step() of the pendulum env (InvertedPendulumEnv.step, envs/inverted_pendulum.py:101-113) in ONE launch: gw_step of the env's
+ * network (two assignable devices, default queue mode; its own CounterTraffic feedback is not produced) + gw_plant_update to the
+ * env's new clock + gw_plant_feedback.  Same results as the three calls.  Any output pointer may be NULL. */
+int gw_pendulum_step(gw_env* env, gw_plant* p, const int32_t* device_dev, const int32_t* duration_dev, int32_t* obs_dev,
+                     float* reward_dev, double* angle_deg_dev, void* stream);
 /* device pointer to the state, double[N][4] (row e = {pos, vel, angle, rate}); valid until gw_plant_destroy */
 int gw_plant_state_ptr(gw_plant* p, double** x_dev);
 /* host copies for tests: "x" f64[N][4] | "u" f64[N] | "t_last" f64[N] | "substeps" u64[N] */

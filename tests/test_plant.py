@@ -125,3 +125,49 @@ def test_inverted_pendulum_env_surface_and_interpreter_formulas():
     assert isinstance(o, int) and isinstance(r, float) and d is False and isinstance(i["Sensor angle"], float)
     with pytest.raises(AssertionError):
         one.step({"device": 2, "duration": 5})
+
+
+@pytest.mark.gpu
+def test_pendulum_env_one_launch_at_config4_size():
+    """BASELINE config 4 at its stated size, 32 768 envs: env.step() as ONE launch (gw_pendulum_step) against
+    (a) the same step issued as two launches -- bit-identical plant state, clocks and feedback;
+    (b) the network's oracle (oracle/ct_oracle.c: clocks, queues, bit-exact) and the plant's oracle (oracle/plant_oracle.c,
+        advanced to the oracle's clocks: <= 1e-5 relative, the north star's bound; observed ~1e-13);
+    (c) the interpreter's formulas evaluated with Python's math on the plant state."""
+    import math
+    import torch
+    from gymwipe_amd import VecInvertedPendulumEnv
+    from gymwipe_amd.actions import actions_torch
+    from oracle.ct_oracle import CtOracle, default_config
+    from oracle.plant_oracle import PlantOracle
+    N, K = 32768, 48
+    fused, split = VecInvertedPendulumEnv(N), VecInvertedPendulumEnv(N)
+    cfg = default_config(2, positions=[(0.0, 0.0), (0.0, -1.0)], rrm_pos=(0.0, 1.0), mult=[1, 0], dest=[1, 0])
+    net = CtOracle(N, 2, config=cfg, nthreads=8)
+    pc = fused.plant.config
+    porc = PlantOracle(N, list(pc.A), list(pc.B), pc.dt, list(pc.x0), pc.u0)
+    a_dev, a_dur = actions_torch(77, 0, N, 0, K, 2, device="cuda")
+    h_dev, h_dur = a_dev.cpu().numpy(), a_dur.cpu().numpy()
+    for k in range(K):
+        act = {"device": a_dev[k], "duration": a_dur[k]}
+        o1, r1, d1, i1 = fused.step(act)
+        o2, r2, d2, i2 = split.step(act, fused=False)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(i1["Sensor angle"], i2["Sensor angle"]), k
+        net.step(h_dev[k], h_dur[k])
+        porc.update(net.get("now"))
+        if k % 16 == 15 or k == K - 1:
+            for f in ("now", "wake", "counter", "qlen", "rx_power"):
+                a, b = fused.network.get_state(f), net.get(f)
+                assert (a.view(np.uint8) == b.view(np.uint8)).all(), (f, k)
+            x = fused.plant.state()
+            assert (x.view(np.uint8) == split.plant.state().view(np.uint8)).all()
+            assert (fused.plant.get_state("substeps") == porc.substeps).all()
+            assert (fused.plant.get_state("t_last") == porc.t_last).all()
+            err = np.abs(x - porc.x) / np.maximum(np.abs(porc.x), 1e-6)
+            assert err.max() < 1e-5, err.max()
+            deg = np.array([math.degrees(a) for a in x[:, 2]])
+            assert (o1.cpu().numpy() == deg.astype(np.int64)).all()
+            np.testing.assert_allclose(r1.cpu().numpy(), np.abs(180.0 - deg).astype(np.float32), rtol=1e-7)
+    assert int(fused.network.get_state("flags").max()) & 3 == 0
+    st = fused.network.stats()
+    assert st["steps"] == N * K and st["transmissions"] > N * K          # announcements + the sensor's packets

@@ -10,7 +10,10 @@ N, D, K, W = int(os.environ.get("N", 65536)), 4, 256, 64
 g = torch.Generator(device="cuda"); g.manual_seed(11)
 dev = torch.randint(0, D, (W + K, N), dtype=torch.int32, device="cuda", generator=g)
 dur = torch.randint(0, 20, (W + K, N), dtype=torch.int32, device="cuda", generator=g)
-for name, kw in (("explicit queues", {}), ("explicit queues + receive-mode MACs", {"peer_receive": True})):
+MODES = (("explicit queues", {}), ("explicit queues + receive-mode MACs", {"peer_receive": True}))
+if os.environ.get("GW_BENCH_MODES") == "plain":      # profiling runs: one mode only
+    MODES = MODES[:1]
+for name, kw in MODES:
     env = gymwipe_amd.VecCounterTrafficEnv(N, D, explicit_queue=True, **kw)
     def run(lo, hi):
         for i in range(lo, hi):

@@ -32,7 +32,7 @@ for f in find("trace", "*kernel_trace.csv"):
         d = sorted(x[0] for x in v)
         print("%s: n=%d avg=%.0f median=%d min=%d max=%d vgpr=%s sgpr=%s wg=%s grid=%s"
               % (k[:80], len(d), sum(d) / len(d), d[len(d) // 2], d[0], d[-1], v[0][1], v[0][2], v[0][3], v[0][4]))
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mem"):
     for f in find(sub, "*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(list))
         with open(f) as fh:
@@ -40,7 +40,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
                 acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print("\n## counters (%s) -- mean per dispatch" % sub)
         for k, cs in acc.items():
-            if not any(w in k for w in ("step", "rollout", "plant", "grid")):
+            if not any(w in k for w in ("step", "rollout", "plant", "grid", "pend")):
                 continue
             for c, vals in sorted(cs.items()):
                 print("%s  %s: n=%d mean=%.1f" % (k[:60], c, len(vals), sum(vals) / len(vals)))

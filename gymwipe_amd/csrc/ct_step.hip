@@ -24,92 +24,20 @@
 // Compile with -ffp-contract=off: every f64 result must be the IEEE result of the
 // reference's individual operations.
 #include "ct_common.hip.h"
+#include "gw_runq.h"
 
 using namespace gwk;
 
 namespace {
 
 
-// One sender's ring during a step.  Appends are never stored one by one: every packet a counter tick appends has the
-// size base + min(ctr0 + tick, bound), so the entries appended in this step are arithmetic in their index and are
-// written once, at the end of the step, as whole 16-byte stores (q_flush).  head/len move as the deque's would.
-struct Ring {
-    uint32_t* base;
-    uint32_t head, len, app;           // app: entries appended in this step so far (not yet in memory)
-};
+// MAC queues: run-length deques, gw_runq.h -- one 16-byte record per (sender, env) holding the runs at both ends, the
+// runs in between in a ring in HBM that a step of counter traffic does not touch.
+__device__ __forceinline__ GwRunQ load_q(const GwRec& r) { return gw_runq_unpack(r); }
+__device__ __forceinline__ GwRec store_q(const GwRunQ& q) { return gw_runq_pack(q); }
 
-// k counter ticks of a sender with multiplicity `mult` (counter_traffic.py:53-61 -> devices.py:84-86 ->
-// simple_stack.py:463-471): drop-oldest on a full deque is the min(), the head moves by the number of drops
-__device__ __forceinline__ void ring_ticks(Ring& r, uint32_t k, uint32_t mult, Tally& t)
-{
-    const uint32_t add = k * mult;
-    const uint32_t want = r.len + add;
-    const uint32_t now = want < (uint32_t)GW_QUEUE_CAP ? want : (uint32_t)GW_QUEUE_CAP;
-    const uint32_t drops = want - now;
-    r.head = (r.head + drops) & GW_RING_MASK;
-    r.len = now;
-    r.app += add;
-    t.app += add;
-    t.drop += drops;
-}
-
-// size of the head packet.  The queue is the last `len` packets of the sender's append stream and this step's appends
-// are its last `app`: the head is one of them iff len <= app (then it is append number app - len, of tick
-// (app - len) / mult); otherwise it is in memory.
-__device__ __forceinline__ uint32_t ring_head_size(const Ring& r, uint32_t inv20, uint32_t ctr0, uint32_t bound, uint32_t base_bytes)
-{
-    if (r.len <= r.app) {
-        const uint32_t tick = ((r.app - r.len) * inv20) >> 20;      // exact: (app - len) * mult < 2^20
-        const uint32_t v = ctr0 + tick;
-        return base_bytes + (v < bound ? v : bound);
-    }
-    return r.base[r.head];
-}
-
-// write this step's appends: entry p (0-based) sits in slot (tail0 + p) & mask and holds base + min(ctr0 + p / mult, bound).
-// Only whole aligned groups of four are stored (the ring is 128 entries, so a group never wraps): the first group keeps
-// the older entries in front of the tail from `head_group`, the copy of it loaded at the start of the step; the last
-// group runs past the new tail with values nothing reads before a later append overwrites them (a full deque still
-// leaves 28 free slots).
-__device__ __forceinline__ void ring_flush(uint32_t* ring, uint32_t tail0, uint32_t app, uint32_t mult, uint32_t inv20,
-                                           uint32_t ctr0, uint32_t bound, uint32_t base_bytes, uint4 head_group)
-{
-    if (app == 0u) return;
-    // more appends than the ring holds (multiplicity > 6): only the last <= 124 can still be live (the deque keeps 100);
-    // start at a group boundary so that the stores cover less than one lap of the ring
-    uint32_t p = 0u;
-    if (app > 124u) { p = app - 124u; p += (4u - ((tail0 + p) & 3u)) & 3u; }
-    uint32_t t = (p * inv20) >> 20;                       // p / mult
-    uint32_t rem = mult - (p - t * mult);                 // copies of tick t still to write
-    uint32_t slot = (tail0 + p) & GW_RING_MASK;
-    auto next = [&]() {
-        const uint32_t v = ctr0 + t;
-        const uint32_t out = base_bytes + (v < bound ? v : bound);
-        if (--rem == 0u) { ++t; rem = mult; }
-        return out;
-    };
-    const uint32_t lead = slot & 3u;                      // older entries in front of the first append, in its group
-    if (lead != 0u) {
-        uint4 v = head_group;
-        if (lead <= 1u) v.y = next();
-        if (lead <= 2u) v.z = next();
-        v.w = next();
-        *reinterpret_cast<uint4*>(ring + (slot & ~3u)) = v;
-        const uint32_t wrote = 4u - lead;
-        p += wrote;
-        slot = (slot + wrote) & GW_RING_MASK;
-    }
-    while (p < app) {
-        uint4 v;
-        v.x = next(); v.y = next(); v.z = next(); v.w = next();
-        *reinterpret_cast<uint4*>(ring + slot) = v;
-        p += 4u;
-        slot = (slot + 4u) & GW_RING_MASK;
-    }
-}
-
-// DT > 0: compile-time sender count -- queue heads/lengths and the 16-byte ring group at every sender's tail are loaded up
-// front into registers (their latency overlaps everything else); DT == 0: any sender count, loaded where needed.
+// DT > 0: compile-time sender count -- every sender's queue record is loaded up front into registers (the latency
+// overlaps everything else); DT == 0: any sender count, loaded where needed.
 template <int DT, bool PER_ENV_STATS>
 __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                                                         const int32_t* __restrict__ device,
@@ -141,18 +69,12 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
     Tally k = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
 
-    // per-sender queue words and tail groups, issued before anything depends on them
+    // per-sender queue records, issued before anything depends on them
     constexpr int DR = DT > 0 ? DT : 1;
-    uint32_t hlv[DR];
-    uint4 hg[DR];
+    GwRec qr[DR];
     if (DT > 0 && e < N) {
 #pragma unroll
-        for (int i = 0; i < DR; ++i) hlv[i] = st.qhl[(int64_t)i * N + e];
-#pragma unroll
-        for (int i = 0; i < DR; ++i) {
-            const uint32_t tail = ((hlv[i] & 0xffu) + (hlv[i] >> 8)) & GW_RING_MASK;
-            hg[i] = *reinterpret_cast<const uint4*>(st.ring + ((((int64_t)e * D + i) << 7) + (tail & ~3u)));
-        }
+        for (int i = 0; i < DR; ++i) qr[i] = st.qrec[(int64_t)i * N + e];
     }
     __syncthreads();
 
@@ -205,20 +127,22 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
             // ---- A.3: window at sender d -----------------------------------------------
-            uint32_t hl_d = 0u;
-            uint4 hg_d = make_uint4(0u, 0u, 0u, 0u);
+            GwRec qr_d = {0u, 0u, 0u, 0u};
             if (DT > 0) {
 #pragma unroll
-                for (int i = 0; i < DR; ++i) { if (i == d) { hl_d = hlv[i]; hg_d = hg[i]; } }
+                for (int i = 0; i < DR; ++i) {
+                    // the words as opaque register values first: a select between array elements by a run-time index is
+                    // folded by the compiler into dynamic addressing of a stack copy of the array
+                    uint32_t w0 = qr[i].x, w1 = qr[i].y, w2 = qr[i].z, w3 = qr[i].w;
+                    asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
+                    const bool hit = i == d;
+                    qr_d.x = hit ? w0 : qr_d.x; qr_d.y = hit ? w1 : qr_d.y; qr_d.z = hit ? w2 : qr_d.z; qr_d.w = hit ? w3 : qr_d.w;
+                }
             } else {
-                hl_d = st.qhl[(int64_t)d * N + e];
+                qr_d = st.qrec[(int64_t)d * N + e];
             }
-            Ring rd;
-            rd.base = st.ring + (((int64_t)e * D + d) << 7);
-            rd.head = hl_d & 0xffu;
-            rd.len = hl_d >> 8;
-            rd.app = 0u;
-            const uint32_t tail0_d = (rd.head + rd.len) & GW_RING_MASK;
+            GwRunQ rd = load_q(qr_d);
+            uint64_t* ring_d = st.runs + (((int64_t)e * D + d) << 7);
             const uint32_t mult_d = (uint32_t)c.mult[d];
             const uint32_t inv20_d = c.inv20[d];
             int n_data = 0;
@@ -240,7 +164,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
 
             // all counter ticks with wake < t (or <= t): counted in f64 four at a time (the running sum w += dt is the
             // reference's arithmetic, counter_traffic.py:61), applied to d's queue in one go
-            auto ticks_to = [&](double t, bool inclusive) {
+            auto ticks_to = [&](double t, bool inclusive) __attribute__((always_inline)) {
                 uint32_t kk = 0;
                 for (;;) {
                     const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
@@ -254,8 +178,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     kk += n;
                     if (!b3) break;
                 }
+                gw_runq_ticks(rd, kk, ctr0 + n_ticks, bound, base_bytes, ring_d, mult_d, inv20_d, k);
                 n_ticks += kk;
-                ring_ticks(rd, kk, mult_d, k);
             };
 
             if (granted) {
@@ -270,15 +194,14 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                         if (mult_d > 0u && wake < stopw) {
                             cur = wake;
                             wake = wake + interval;
+                            gw_runq_ticks(rd, 1u, ctr0 + n_ticks, bound, base_bytes, ring_d, mult_d, inv20_d, k);
                             n_ticks++;
-                            ring_ticks(rd, 1u, mult_d, k);
                         } else break;
                     }
-                    const uint32_t s = ring_head_size(rd, inv20_d, ctr0, bound, base_bytes);
+                    const uint32_t s = rd.H.v0;                           // the head run's first packet
                     const double need = m.over_rate((double)(s * 8u));    // messages.py:67-75
                     if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
-                    rd.head = (rd.head + 1u) & GW_RING_MASK;              // :425
-                    rd.len--;
+                    gw_runq_pop_front(rd, 1u, ring_d, mult_d, inv20_d, base_bytes + bound);   // :425
                     k.pop++;
                     const int pay = (int)s - mh;
                     const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
@@ -320,34 +243,23 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 bool tiej = false;
                 if (c.fast_ticks && gw_tick_jump(wake, t_end, interval, c.inv_interval, true, &nj, &wj, &tiej)) {
                     wake = wj;
-                    n_ticks += nj;
                     if (tiej) fl |= GW_FLAG_TIE;
-                    ring_ticks(rd, nj, mult_d, k);
+                    gw_runq_ticks(rd, nj, ctr0 + n_ticks, bound, base_bytes, ring_d, mult_d, inv20_d, k);
+                    n_ticks += nj;
                 } else {
                     ticks_to(t_end, true);
                 }
             }
-            st.qhl[(int64_t)d * N + e] = (uint16_t)(rd.head | (rd.len << 8));
-            if (DT == 0 && rd.app != 0u && (tail0_d & 3u) != 0u) hg_d = *reinterpret_cast<const uint4*>(rd.base + (tail0_d & ~3u));
-            ring_flush(rd.base, tail0_d, rd.app, mult_d, inv20_d, ctr0, bound, base_bytes, hg_d);
+            st.qrec[(int64_t)d * N + e] = store_q(rd);
 #pragma unroll
             for (int i = 0; i < (DT > 0 ? DT : D); ++i) {
                 if (i == d) continue;
                 // the same n_ticks ticks d's walk just counted (all senders tick together)
-                const uint32_t hl = DT > 0 ? hlv[DT > 0 ? i : 0] : (uint32_t)st.qhl[(int64_t)i * N + e];
-                Ring ri;
-                ri.base = st.ring + (((int64_t)e * D + i) << 7);
-                ri.head = hl & 0xffu;
-                ri.len = hl >> 8;
-                ri.app = 0u;
-                const uint32_t tail0 = (ri.head + ri.len) & GW_RING_MASK;
                 const uint32_t mult_i = (uint32_t)c.mult[i];
                 if (n_ticks != 0u && mult_i != 0u) {
-                    ring_ticks(ri, n_ticks, mult_i, k);
-                    st.qhl[(int64_t)i * N + e] = (uint16_t)(ri.head | (ri.len << 8));
-                    uint4 hgi = DT > 0 ? hg[DT > 0 ? i : 0] : make_uint4(0u, 0u, 0u, 0u);
-                    if (DT == 0 && (tail0 & 3u) != 0u) hgi = *reinterpret_cast<const uint4*>(ri.base + (tail0 & ~3u));
-                    ring_flush(ri.base, tail0, ri.app, mult_i, c.inv20[i], ctr0, bound, base_bytes, hgi);
+                    GwRunQ ri = load_q(DT > 0 ? qr[DT > 0 ? i : 0] : st.qrec[(int64_t)i * N + e]);
+                    gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, c.inv20[i], k);
+                    st.qrec[(int64_t)i * N + e] = store_q(ri);
                 }
             }
             uint32_t ctr_new = ctr0 + n_ticks;                            // `if counter < bound: counter += 1` per tick
@@ -418,7 +330,7 @@ __global__ void ct_init_kernel(GwState st)
     st.last_abs[e] = 0;
     st.done[e] = 0;
     st.flags[e] = 0u;
-    if (st.qhl) for (int i = 0; i < D; ++i) st.qhl[(int64_t)i * N + e] = 0;
+    if (st.qrec) for (int i = 0; i < D; ++i) st.qrec[(int64_t)i * N + e] = GwRec{0u, 0u, 0u, 0u};
     for (int r = 0; r < R; ++r) st.rxs[(int64_t)r * N + e] = 0;
     if (st.pe_stats) for (int s = 0; s < 5; ++s) st.pe_stats[(int64_t)s * N + e] = 0ull;
     if (st.peer_rx) for (int i = 0; i < D; ++i) st.peer_rx[(int64_t)i * N + e] = 0u;
@@ -434,17 +346,15 @@ __global__ void ct_enqueue_kernel(GwState st, int sender, const int32_t* __restr
     const int32_t pb = payload_bytes[e];
     if (pb < 0) return;
     const GwDevConst& c = *st.cst;
-    const uint16_t hl = st.qhl[(int64_t)sender * N + e];
-    uint32_t* ring = st.ring + (((int64_t)e * c.D + sender) << 7);
-    uint32_t head = hl & 0xffu, len = hl >> 8, dropped = 0u;
-    if (len == (uint32_t)GW_QUEUE_CAP) {                  // deque(maxlen=100): drop the oldest
-        head = (head + 1u) & GW_RING_MASK;
-        len--;
+    GwRunQ q = load_q(st.qrec[(int64_t)sender * N + e]);
+    uint64_t* ring = st.runs + (((int64_t)e * c.D + sender) << 7);
+    uint32_t dropped = 0u;
+    if (q.len == (uint32_t)GW_QUEUE_CAP) {                // deque(maxlen=100): drop the oldest
+        gw_runq_pop_front(q, 1u, ring, (uint32_t)c.mult[sender], c.inv20[sender], (uint32_t)(c.mac_hdr + c.net_hdr + c.counter_bound));
         dropped = 1u;
     }
-    ring[(head + len) & GW_RING_MASK] = (uint32_t)(c.mac_hdr + c.net_hdr + pb);
-    len++;
-    st.qhl[(int64_t)sender * N + e] = (uint16_t)(head | (len << 8));
+    gw_runq_append_literal(q, (uint32_t)(c.mac_hdr + c.net_hdr + pb), ring);
+    st.qrec[(int64_t)sender * N + e] = store_q(q);
     if (st.pe_stats) { st.pe_stats[2 * N + e] += 1u; st.pe_stats[4 * N + e] += dropped; }
 }
 

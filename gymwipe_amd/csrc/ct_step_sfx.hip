@@ -499,6 +499,10 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     const double2 x23 = *reinterpret_cast<const double2*>(p.x + el * 4 + 2);
     const double u = p.u[el];
     const double tl = p.t_last[el];
+    const unsigned long long nsub0 = p.nsub[el];
+    double p_op[GW_PLANT_KMAX / 4], q_op[GW_PLANT_KMAX / 4];       // MFMA A operands of every candidate group, by lane
+#pragma unroll
+    for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) { p_op[grp] = p.Pop[grp * 64 + lane]; q_op[grp] = p.Qop[grp * 64 + lane]; }
 
     double now_new;
     bool live;
@@ -510,30 +514,46 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     s_x[lane][0] = x01.x; s_x[lane][1] = x01.y; s_x[lane][2] = x23.x; s_x[lane][3] = x23.y;
     __syncthreads();
     const int g = lane >> 4, col = lane & 15;
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {                        // 16 envs of the wave per round
+    // four rounds of 16 envs, interleaved: the rounds' MFMA chains are independent, so they issue back to back
+    double xg[4], ug[4];
+    int nq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
         const int src = 16 * q + col;
-        double xg = s_x[src][g];
+        xg[q] = s_x[src][g];
         const double uq = __shfl(u, src);
-        const double ug = (g == 0) ? uq : 0.0;           // B operand of the input MFMA: row 0 = u
-        int nq = __shfl(n, src);
-        while (__any(nq > 0)) {
-            const int chunk = nq > GW_PLANT_KMAX ? GW_PLANT_KMAX : nq;     // this round's substeps (0 = done)
-            double xn = xg;
-            for (int grp = 0; grp < GW_PLANT_KMAX / 4 && __any(chunk > 4 * grp); ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
-                const double a_p = p.Pop[grp * 64 + lane];
-                const double a_q = p.Qop[grp * 64 + lane];
-                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_q, ug, acc, 0, 0, 0);
-                const int r = chunk - (4 * grp + 1);                 // which candidate is mine (if any)
-                if (r >= 0 && r < 4) xn = r == 0 ? acc.x : (r == 1 ? acc.y : (r == 2 ? acc.z : acc.w));
-            }
-            xg = xn;
-            nq -= chunk;
-        }
-        s_x[src][g] = xg;
+        ug[q] = (g == 0) ? uq : 0.0;                     // B operand of the input MFMA: row 0 = u
+        nq[q] = __shfl(n, src);
     }
+    int nmax = n;                                        // wave-wide maximum of the substep counts
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
+    while (nmax > 0) {                                   // one pass unless an env needs more than GW_PLANT_KMAX substeps
+        const int cmax = nmax > GW_PLANT_KMAX ? GW_PLANT_KMAX : nmax;
+        int chunk[4];
+        double xn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { chunk[q] = nq[q] > GW_PLANT_KMAX ? GW_PLANT_KMAX : nq[q]; xn[q] = xg[q]; }
+#pragma unroll
+        for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
+            if (cmax > 4 * grp) {                        // wave-uniform
+                const double a_p = p_op[grp], a_q = q_op[grp];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg[q], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_q, ug[q], acc, 0, 0, 0);
+                    const int r = chunk[q] - (4 * grp + 1);           // which candidate is mine (if any)
+                    if (r >= 0 && r < 4) xn[q] = r == 0 ? acc.x : (r == 1 ? acc.y : (r == 2 ? acc.z : acc.w));
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xg[q] = xn[q]; nq[q] -= chunk[q]; }
+        nmax -= cmax;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_x[16 * q + col][g] = xg[q];
     __syncthreads();
     if (mine) {
         const double a0 = s_x[lane][0], a1 = s_x[lane][1], a2 = s_x[lane][2], a3 = s_x[lane][3];
@@ -541,7 +561,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
             *reinterpret_cast<double2*>(p.x + e * 4) = make_double2(a0, a1);
             *reinterpret_cast<double2*>(p.x + e * 4 + 2) = make_double2(a2, a3);
             p.t_last[e] = now_new;
-            p.nsub[e] += (unsigned long long)n;
+            p.nsub[e] = nsub0 + (unsigned long long)n;
         }
         const double deg = a2 * (180.0 / 3.141592653589793);        // envs/inverted_pendulum.py:27-57
         if (obs) obs[e] = (int32_t)deg;

@@ -4,6 +4,7 @@
 // entry point fails with GW_ENODEVICE.
 #include "gw_internal.h"
 #include "gw_queue.h"
+#include "gw_runq.h"
 #include "gw_fastmath.h"
 
 #include <hip/hip_runtime.h>
@@ -333,7 +334,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr; uint8_t* d_blob = nullptr;
     if (explicit_q) {
         TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
-        TRY_ALLOC(st.qhl, N * D);  TRY_ALLOC(st.ring, N * D * GW_RING_PHYS);
+        TRY_ALLOC(st.qrec, N * D);  TRY_ALLOC(st.runs, N * D * GW_RING_PHYS);
         TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
         TRY_ALLOC(st.rxs, N * R);
     } else {
@@ -404,7 +405,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
         HIP_TRY_D(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
     if (st.totals) HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
-    if (st.ring) HIP_TRY_D(hipMemset(st.ring, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint32_t)));
+    if (st.runs) HIP_TRY_D(hipMemset(st.runs, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint64_t)));
     if (st.bph) HIP_TRY_D(hipMemset(st.bph, 0, (size_t)N * GW_RING_PHYS * sizeof(GwBp)));
     rc = explicit_q ? gw_launch_init(st, nullptr) : gw_launch_init_sfx(st, nullptr);
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
@@ -489,7 +490,7 @@ int gw_delivered(gw_env* env, uint32_t* out_dev, void* stream)
 int gw_enqueue(gw_env* env, int32_t sender, const int32_t* payload_bytes_dev, void* stream)
 {
     if (!env || !payload_bytes_dev) return fail(GW_EINVAL, "env/payload_bytes is NULL");
-    if (!env->st.ring) return fail(GW_EUNSUPPORTED, "gw_enqueue needs GW_CFG_EXPLICIT_QUEUE");
+    if (!env->st.runs) return fail(GW_EUNSUPPORTED, "gw_enqueue needs GW_CFG_EXPLICIT_QUEUE");
     if (sender < 0 || sender >= env->st.D) return fail(GW_EINVAL, "sender out of range");
     int rc = select_device(env);
     if (rc) return rc;
@@ -697,6 +698,67 @@ int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t c
     return (int)bad;
 }
 
+// Host-only fuzz of the run-length queues (gw_runq.h, the same code the generic kernel runs) against an explicit
+// deque(maxlen=GW_QUEUE_CAP): random counter ticks (with a saturating counter and resets), pops, and literal packets.
+// Returns the number of mismatches (0 = identical), negative on bad arguments.
+int gw_selftest_runq(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound)
+{
+    if (operations < 0 || mult < 1 || mult > GW_QUEUE_CAP || counter_bound < 1) return fail(GW_EINVAL, "gw_selftest_runq: bad arguments");
+    uint64_t x = seed * 6364136223846793005ull + 1442695040888963407ull;
+    auto rnd = [&x](uint32_t n) {
+        x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+        return (uint32_t)(((x * 2685821657736338717ull) >> 33) % n);
+    };
+    const uint32_t m = (uint32_t)mult, bound = (uint32_t)counter_bound, base = 25u, cap = base + bound;
+    const uint32_t inv20 = ((1u << 20) + m - 1u) / m;
+    std::vector<uint64_t> ring(GW_RING_PHYS, 0);
+    GwRec zero = {0u, 0u, 0u, 0u};
+    GwRunQ q = gw_runq_unpack(zero);
+    std::deque<uint32_t> ref;
+    GwTally tally = {0, 0, 0, 0, 0};
+    uint64_t ref_drops = 0, ref_apps = 0;
+    uint32_t ctr = 1, bad = 0;
+    for (int32_t op = 0; op < operations; ++op) {
+        const uint32_t what = rnd(16);
+        if (what < 8) {                                   // k counter ticks
+            const uint32_t k = 1 + rnd(what < 5 ? 3 : 22);
+            uint32_t c = ctr;
+            for (uint32_t t = 0; t < k; ++t) {
+                for (uint32_t j = 0; j < m; ++j) {
+                    if (ref.size() == GW_QUEUE_CAP) { ref.pop_front(); ++ref_drops; }
+                    ref.push_back(base + c);
+                    ++ref_apps;
+                }
+                if (c < bound) ++c;
+            }
+            gw_runq_ticks(q, k, ctr, bound, base, ring.data(), m, inv20, tally);
+            ctr = c;
+        } else if (what < 10) {                           // reset(): counters restart
+            ctr = 0;
+        } else if (what < 12) {                           // SimpleNetworkDevice.send of an arbitrary packet
+            const uint32_t size = 1 + rnd(70000);
+            if (ref.size() == GW_QUEUE_CAP) { ref.pop_front(); gw_runq_pop_front(q, 1u, ring.data(), m, inv20, cap); }
+            ref.push_back(size);
+            gw_runq_append_literal(q, size, ring.data());
+        } else {                                          // window pops
+            uint32_t n = 1 + rnd(what == 15 ? 60 : 4);
+            while (n-- && !ref.empty()) {
+                if (q.len != ref.size() || q.state == 0u || q.H.v0 != ref.front()) ++bad;
+                ref.pop_front();
+                gw_runq_pop_front(q, 1u, ring.data(), m, inv20, cap);
+            }
+        }
+        q = gw_runq_unpack(gw_runq_pack(q));              // through the 16-byte record, as between two steps
+        uint32_t out[GW_QUEUE_CAP];
+        const uint32_t n = gw_runq_expand(q, ring.data(), m, cap, out);
+        bool same = n == ref.size() && q.len == ref.size();
+        for (uint32_t p = 0; same && p < n; ++p) same = out[p] == ref[p];
+        if (!same) ++bad;
+    }
+    if (tally.drop != ref_drops || tally.app != ref_apps) ++bad;
+    return (int)bad;
+}
+
 int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
 {
     if (!env || !field || !dst) return fail(GW_EINVAL, "env/field/dst is NULL");
@@ -830,24 +892,27 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         return GW_OK;
     }
     if (!strcmp(field, "qlen") || !strcmp(field, "queue")) {
-        std::vector<uint16_t> hl((size_t)N * D);
-        HIP_TRY(hipMemcpy(hl.data(), st.qhl, hl.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        std::vector<GwRec> rec((size_t)N * D);
+        HIP_TRY(hipMemcpy(rec.data(), st.qrec, rec.size() * sizeof(GwRec), hipMemcpyDeviceToHost));
         if (field[1] == 'l') {
             NEED(N * D, int32_t);
             int32_t* o = (int32_t*)dst;
-            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = hl[(size_t)i * N + e] >> 8;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = (int32_t)(rec[(size_t)i * N + e].w >> 24);
             return GW_OK;
         }
         NEED(N * D * GW_QUEUE_CAP, uint32_t);
-        std::vector<uint32_t> ring((size_t)N * D * GW_RING_PHYS);
-        HIP_TRY(hipMemcpy(ring.data(), st.ring, ring.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint64_t> runs((size_t)N * D * GW_RING_PHYS);
+        HIP_TRY(hipMemcpy(runs.data(), st.runs, runs.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         uint32_t* o = (uint32_t*)dst;
+        memset(o, 0, bytes);
+        const uint32_t cap = (uint32_t)(env->cfg.mac_header_bytes + env->cfg.net_header_bytes + env->cfg.counter_bound);
         for (int64_t e = 0; e < N; ++e)
             for (int i = 0; i < D; ++i) {
-                const int head = hl[(size_t)i * N + e] & 0xff, len = hl[(size_t)i * N + e] >> 8;
-                const uint32_t* r = ring.data() + ((size_t)e * D + i) * GW_RING_PHYS;
-                uint32_t* q = o + ((size_t)e * D + i) * GW_QUEUE_CAP;
-                for (int s = 0; s < GW_QUEUE_CAP; ++s) q[s] = s < len ? r[(head + s) & GW_RING_MASK] : 0u;
+                const GwRunQ q = gw_runq_unpack(rec[(size_t)i * N + e]);
+                const uint32_t mult = env->cfg.mult[i] > 0 ? (uint32_t)env->cfg.mult[i] : 1u;
+                const uint32_t n = gw_runq_expand(q, runs.data() + ((size_t)e * D + i) * GW_RING_PHYS, mult, cap,
+                                                  o + ((size_t)e * D + i) * GW_QUEUE_CAP);
+                if (n != q.len) return fail(GW_EHIP, "internal: queue record of env %lld sender %d is inconsistent", (long long)e, i);
             }
         return GW_OK;
     }

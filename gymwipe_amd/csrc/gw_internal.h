@@ -36,6 +36,7 @@ struct GwDevConst {
 };
 
 struct GwBp { uint32_t t0, c0; };        // counting restarts at tick t0 with counter value c0
+struct alignas(16) GwRec { uint32_t x, y, z, w; };   // a run-length queue's 16-byte record (gw_runq.h)
 
 // Per-handle device state (structure of arrays; N = num_envs, D senders, R = D+1 radios).
 struct GwState {
@@ -46,9 +47,9 @@ struct GwState {
     double*   wake;       // [N]        next counter tick (all senders tick in lock-step)
     uint32_t* counter;    // [N]        sender.counter (identical for all senders of an env)
     // MAC queue (SimpleMac._packetQueue), one of two encodings:
-    //  explicit (GW_CFG_EXPLICIT_QUEUE): a ring of packet byte sizes
-    uint16_t* qhl;        // [D][N]     ring head (low byte) | length (high byte)
-    uint32_t* ring;       // [N][D][GW_RING_PHYS]  packet byte sizes
+    //  explicit (GW_CFG_EXPLICIT_QUEUE): run-length deques, gw_runq.h
+    GwRec*    qrec;       // [D][N]     16-byte record: head run, tail run, bookkeeping
+    uint64_t* runs;       // [N][D][GW_RING_PHYS]  the runs in between (touched only when a run is created or used up)
     //  suffix (default): see gw_queue.h.  Packed so that one env costs four 16-byte loads:
     double*   tw;         // [N][2]     {now, next counter tick}
     uint32_t* tk;         // [N][4]     {tau = ticks so far, nbp = breakpoints so far, newest breakpoint (t0, c0)}

@@ -109,8 +109,8 @@ typedef struct gw_config {
 
 #define GW_CFG_PER_ENV_STATS  1             /* explicit-queue mode only: keep per-env event counters (the default
                                                mode always keeps them, as 32-bit counters that wrap) */
-#define GW_CFG_EXPLICIT_QUEUE 2             /* MAC queues as explicit rings of packet sizes (generic, slower);
-                                               default: exact suffix encoding of counter traffic, gw_queue.h */
+#define GW_CFG_EXPLICIT_QUEUE 2             /* MAC queues as deques of packet-size runs that hold ANY traffic (generic kernel,
+                                               gw_runq.h); default: exact suffix encoding of counter traffic, gw_queue.h */
 
 /* The three flags below widen the path towards the callers SURVEY 8f ranks next (receive-mode MACs and
  * traffic other than counters); they need GW_CFG_EXPLICIT_QUEUE.  Together they replay the reference's
@@ -333,6 +333,10 @@ int gw_ctrl_get_state(gw_ctrl* c, const char* field, void* dst_host, size_t byte
 /* Host-only self-test hook (no GPU needed): fuzzes the MAC-queue encoding the default kernel uses
  * against an explicit deque(maxlen=100).  Returns the number of mismatches (0 = identical). */
 int gw_selftest_queue(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);
+
+/* Host-only: the same fuzz for the run-length queues of the generic kernel (GW_CFG_EXPLICIT_QUEUE, csrc/gw_runq.h): counter ticks,
+ * resets, pops and arbitrary gw_enqueue packets; mult up to GW_QUEUE_CAP.  Returns the number of mismatches. */
+int gw_selftest_runq(uint64_t seed, int32_t operations, int32_t mult, int32_t counter_bound);
 
 /* Host-only: bit mask of the exact arithmetic fast paths gw_create enables for cfg after validating
  * them (1 slot remainder, 2 division by the data rate, 4 integer decode decision, 8 idempotent

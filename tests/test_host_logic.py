@@ -60,6 +60,13 @@ def test_queue_encoding_fuzz_against_explicit_deque(native_lib, mult, bound):
         assert native_lib.gw_selftest_queue(seed, 30000, mult, bound) == 0
 
 
+@pytest.mark.parametrize("mult,bound", [(1, 65536), (3, 65536), (3, 40), (2, 7), (15, 1), (5, 300), (37, 65536), (100, 65536), (64, 9)])
+def test_run_length_queue_fuzz_against_explicit_deque(native_lib, mult, bound):
+    """gw_runq.h (the generic kernel's queues) vs deque(maxlen=100): ticks, resets, pops, arbitrary enqueued packets."""
+    for seed in range(3):
+        assert native_lib.gw_selftest_runq(seed, 30000, mult, bound) == 0
+
+
 def test_fast_paths_validate_for_default_configs(native_lib):
     from gymwipe_amd import _native
     for D, want_states in ((2, 3), (4, 4), (16, 6), (32, 8)):

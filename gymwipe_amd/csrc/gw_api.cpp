@@ -63,6 +63,7 @@ struct gw_env {
     int          nblocks;
     uint64_t     bytes;
     uint32_t*    pack_bad;    // device counter: elements gw_pack_feedback could not represent
+    int          dyn;         // live-PHY mode (ct_step_dyn.hip): per-env geometry, or a geometry without a finite noise-state set
 };
 
 namespace {
@@ -116,6 +117,8 @@ int validate(const gw_config& c)
     }
     if ((c.flags & (GW_CFG_NO_COUNTER_TRAFFIC | GW_CFG_PEER_RECEIVE | GW_CFG_FLOAT_DURATION)) && !(c.flags & GW_CFG_EXPLICIT_QUEUE))
         return fail(GW_EUNSUPPORTED, "GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION need GW_CFG_EXPLICIT_QUEUE");
+    if ((c.flags & GW_CFG_PER_ENV_GEOMETRY) && (c.flags & GW_CFG_EXPLICIT_QUEUE))
+        return fail(GW_EUNSUPPORTED, "GW_CFG_PER_ENV_GEOMETRY needs the default queue mode");
     for (int a = 0; a <= c.num_devices; ++a)
         for (int b = 0; b <= c.num_devices; ++b)
             if (!(c.extra_att_db[a][b] == c.extra_att_db[b][a]) || (a == b && c.extra_att_db[a][b] != 0.0))
@@ -162,12 +165,14 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
                 if (s1 != s2) { k.idem_states = 0; break; }
             }
         }
+    if (tab.overflow) k.idem_states = 0;
     if (getenv("GW_NO_IDEM")) k.idem_states = 0;    // test switch: take the exact-count path although the map is idempotent
 }
 
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
                 int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
+    if (env->dyn) return gw_launch_step_dyn(env->st, env->cst_host, device, duration, obs, reward, done, stream);
     return env->st.tk ? gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, stream)
                       : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
@@ -196,6 +201,9 @@ int gw_fill_dev_const(const gw_config& cfg, const GwHostTables& tab, GwDevConst&
     k.duration_factor = cfg.duration_factor; k.max_duration = cfg.max_duration;
     for (int i = 0; i < D; ++i) { k.mult[i] = cfg.mult[i]; k.inv16[i] = cfg.mult[i] > 0 ? (65536u + (uint32_t)cfg.mult[i] - 1u) / (uint32_t)cfg.mult[i] : 0u; }
     for (int i = 0; i < D; ++i) k.inv20[i] = cfg.mult[i] > 0 ? ((1u << 20) + (uint32_t)cfg.mult[i] - 1u) / (uint32_t)cfg.mult[i] : 0u;
+    k.ten_log_br = 10 * log10(cfg.bit_rate);            // physical.py:38-42 (the same libm call CPython makes)
+    k.twenty_log_f = 20 * log10(cfg.frequency);         // attenuation_models.py:35
+    k.tx_power_dbm = cfg.tx_power_dbm;
     k.start_time = cfg.start_time;
     k.no_traffic = (cfg.flags & GW_CFG_NO_COUNTER_TRAFFIC) ? 1 : 0;
     k.peer_receive = (cfg.flags & GW_CFG_PEER_RECEIVE) ? 1 : 0;
@@ -229,6 +237,7 @@ int gw_validate_config(const gw_config& cfg) { return validate(cfg); }
 int gw_env_internals(gw_env* env, const GwState** st, const GwDevConst** cst, int* hip_device)
 {
     if (!env) return fail(GW_EINVAL, "env is NULL");
+    if (env->dyn) return fail(GW_EUNSUPPORTED, "not available in the live-PHY mode (per-env geometry / open noise-state set)");
     *st = &env->st; *cst = &env->cst_host; *hip_device = env->cfg.hip_device;
     return GW_OK;
 }
@@ -331,6 +340,12 @@ int gw_create(const gw_config* cfg, gw_env** out)
     const size_t tcount = (size_t)R * R * GW_MAX_NSTATES;
 #define TRY_ALLOC(ptr, count) do { rc = dev_alloc(env, &(ptr), (size_t)(count)); if (rc) { gw_destroy(env); return rc; } } while (0)
     const bool explicit_q = (cfg->flags & GW_CFG_EXPLICIT_QUEUE) != 0;
+    const bool per_env_geo = (cfg->flags & GW_CFG_PER_ENV_GEOMETRY) != 0;
+    env->dyn = (per_env_geo || env->tab.overflow) ? 1 : 0;
+    if (env->dyn && explicit_q) {
+        gw_destroy(env);
+        return fail(GW_EUNSUPPORTED, "%s: this geometry needs the live-PHY kernel, which runs in the default queue mode only", msg);
+    }
     uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr; uint8_t* d_blob = nullptr;
     if (explicit_q) {
         TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
@@ -350,6 +365,12 @@ int gw_create(const gw_config* cfg, gw_env** out)
             st.rcap = (cap + 15) / 16 * 16;
             if (st.rcap > 0) { TRY_ALLOC(st.ract, N * st.rcap);  TRY_ALLOC(st.rfb, N * st.rcap); }
         }
+    }
+    double *d_prx = nullptr, *d_pos = nullptr, *d_extra = nullptr;
+    if (env->dyn) {
+        TRY_ALLOC(st.rxp, N * R);  TRY_ALLOC(d_prx, R * R);  TRY_ALLOC(d_pos, R * 2);  TRY_ALLOC(d_extra, R * R);
+        if (per_env_geo) { TRY_ALLOC(st.prx_env, N * R * R);  TRY_ALLOC(st.pos_env, N * R * 2); }
+        st.prx_tab = d_prx; st.pos_tab = d_pos; st.extra_tab = d_extra;
     }
     if (explicit_q) TRY_ALLOC(st.flags, N);
     if (explicit_q && (cfg->flags & GW_CFG_PEER_RECEIVE)) TRY_ALLOC(st.peer_rx, N * D);
@@ -407,7 +428,18 @@ int gw_create(const gw_config* cfg, gw_env** out)
     if (st.totals) HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.runs) HIP_TRY_D(hipMemset(st.runs, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint64_t)));
     if (st.bph) HIP_TRY_D(hipMemset(st.bph, 0, (size_t)N * GW_RING_PHYS * sizeof(GwBp)));
+    if (env->dyn) {
+        std::vector<double> prx((size_t)R * R, 0.0), pos((size_t)R * 2), ext((size_t)R * R, 0.0);
+        for (int a = 0; a < R; ++a) {
+            pos[(size_t)a * 2] = cfg->pos[a][0]; pos[(size_t)a * 2 + 1] = cfg->pos[a][1];
+            for (int b = 0; b < R; ++b) { prx[(size_t)a * R + b] = env->tab.prx[a][b]; ext[(size_t)a * R + b] = cfg->extra_att_db[a][b]; }
+        }
+        HIP_TRY_D(hipMemcpy(d_prx, prx.data(), prx.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY_D(hipMemcpy(d_pos, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY_D(hipMemcpy(d_extra, ext.data(), ext.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     rc = explicit_q ? gw_launch_init(st, nullptr) : gw_launch_init_sfx(st, nullptr);
+    if (!rc && env->dyn) rc = gw_launch_init_dyn(st, k, env->tab.thermal, nullptr);
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
     HIP_TRY_D(hipDeviceSynchronize());
 #undef HIP_TRY_D
@@ -460,7 +492,7 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
     const int64_t N = env->st.N;
     int32_t s = 0;
     // fused persistent rollout (ct_rollout_sfx.hip) in chunks of up to rcap steps, when this D has one
-    while (env->st.tk && env->st.rcap > 0 && s < steps) {
+    while (env->st.tk && !env->dyn && env->st.rcap > 0 && s < steps) {
         const int32_t chunk = steps - s < env->st.rcap ? steps - s : env->st.rcap;
         const int64_t o = (int64_t)s * N;
         rc = gw_launch_rollout_sfx(env->st, env->cst_host, chunk, device_dev + o, duration_dev + o, obs_dev + o,
@@ -531,6 +563,29 @@ int gw_unpack_feedback(gw_env* env, int64_t count, const uint8_t* packed_dev, in
     if (rc) return rc;
     if (gw_launch_unpack_feedback(count, env->cfg.counter_bound, env->cfg.payload_value, packed_dev, obs_dev, reward_dev, done_dev, stream))
         return fail(GW_EHIP, "unpack kernel launch failed");
+    return GW_OK;
+}
+
+int gw_set_position(gw_env* env, int32_t radio, const double* x_dev, const double* y_dev, const uint8_t* mask_dev, void* stream)
+{
+    if (!env || !x_dev || !y_dev) return fail(GW_EINVAL, "env/x/y is NULL");
+    if (!env->st.prx_env) return fail(GW_EUNSUPPORTED, "gw_set_position needs GW_CFG_PER_ENV_GEOMETRY");
+    if (radio < 0 || radio > env->st.D) return fail(GW_EINVAL, "radio index out of range");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_set_position(env->st, env->cst_host, radio, x_dev, y_dev, nullptr, mask_dev, stream))
+        return fail(GW_EHIP, "set_position kernel launch failed");
+    return GW_OK;
+}
+
+int gw_set_positions(gw_env* env, const double* pos_dev, const uint8_t* mask_dev, void* stream)
+{
+    if (!env || !pos_dev) return fail(GW_EINVAL, "env/pos is NULL");
+    if (!env->st.prx_env) return fail(GW_EUNSUPPORTED, "gw_set_positions needs GW_CFG_PER_ENV_GEOMETRY");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_set_position(env->st, env->cst_host, -1, nullptr, nullptr, pos_dev, mask_dev, stream))
+        return fail(GW_EHIP, "set_position kernel launch failed");
     return GW_OK;
 }
 
@@ -626,6 +681,7 @@ int gw_selftest_fastmath(const gw_config* cfg, int32_t* max_noise_states)
     set_fast_paths(*cfg, *tab, k);
     int mx = 0;
     for (int r = 0; r < tab->R; ++r) mx = tab->nstates[r] > mx ? tab->nstates[r] : mx;
+    if (tab->overflow) mx = GW_MAX_NSTATES + 1;           // no finite state set: the live-PHY kernel takes this geometry
     if (max_noise_states) *max_noise_states = mx;
     delete tab;
     return (k.fast_fmod ? 1 : 0) | (k.fast_div ? 2 : 0) | (k.fast_decide ? 4 : 0) | (k.idem_states ? 8 : 0) | (k.fast_ticks ? 16 : 0);
@@ -834,7 +890,22 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         }
         if (!strcmp(field, "rx_power")) {
             NEED(N * R, double); double* o = (double*)dst;
+            if (st.rxp) {                            // live-PHY mode: the f64 itself, [R][N] on the device
+                std::vector<double> rx((size_t)N * R);
+                HIP_TRY(hipMemcpy(rx.data(), st.rxp, rx.size() * sizeof(double), hipMemcpyDeviceToHost));
+                for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = rx[(size_t)r * N + e];
+                return GW_OK;
+            }
             for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = env->tab.state_val[r][qb[(size_t)e * RB + D + r]];
+            return GW_OK;
+        }
+        if (!strcmp(field, "pos") || !strcmp(field, "link_power")) {
+            if (!st.prx_env) return fail(GW_EFIELD, "field %s needs GW_CFG_PER_ENV_GEOMETRY", field);
+            const int per = field[0] == 'p' ? R * 2 : R * R;
+            NEED(N * per, double); double* o = (double*)dst;
+            std::vector<double> v((size_t)N * per);
+            HIP_TRY(hipMemcpy(v.data(), field[0] == 'p' ? st.pos_env : st.prx_env, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < per; ++i) o[e * per + i] = v[(size_t)i * N + e];
             return GW_OK;
         }
         if (!strcmp(field, "queue")) {

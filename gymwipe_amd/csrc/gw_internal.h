@@ -32,6 +32,7 @@ struct GwDevConst {
     double  tie_filter;                 // a tick can only fall exactly on t when (t - wake)/interval is this close to an integer
     int32_t no_traffic, peer_receive, float_duration;   // GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION
     int32_t dest[GW_MAX_DEVICES];
+    double  ten_log_br, twenty_log_f, tx_power_dbm;   // 10*log10(bit_rate), 20*log10(frequency) (host glibc), tx power: live-PHY kernel
     uint32_t inv20[GW_MAX_DEVICES];     // ceil(2^20 / mult[i]): p / mult for p * mult < 2^20 (generic kernel's append index -> tick)
 };
 
@@ -82,6 +83,13 @@ struct GwState {
     const double*     ber2;      // [2][D][S]
     const uint8_t*    cls2;      // [2][D][S]
     const uint8_t*    blob;      // GwBlobLayout: the default step kernel's tables in one block
+    // live-PHY mode (ct_step_dyn.hip): f64 received power per radio instead of the noise-state bytes
+    double*   rxp;        // [R][N]     phy._receivedPower, or nullptr (default mode)
+    const double* prx_tab;   // [R][R]  link power from -> to, mW (host glibc tables)
+    const double* pos_tab;   // [R][2]  the handle's geometry
+    const double* extra_tab; // [R][R]  custom attenuation per pair, dB
+    double*   prx_env;    // [R][R][N]  per-env link powers (GW_CFG_PER_ENV_GEOMETRY), else nullptr
+    double*   pos_env;    // [R][2][N]  per-env positions
 };
 
 // byte offsets inside GwState::blob (the default step kernel's tables; see ct_step_sfx.hip)
@@ -169,6 +177,7 @@ struct GwHostTables {
     double prx[GW_MAX_RADIOS][GW_MAX_RADIOS];        // mW, [from][to]
     double thermal;                                   // mW
     double data_rate, coded_factor;
+    int    overflow;                                  // some radio's state closure exceeds GW_MAX_NSTATES: live-PHY kernel
     int    nstates[GW_MAX_RADIOS];
     double state_val[GW_MAX_RADIOS][GW_MAX_NSTATES];  // mW; index 0 = thermal
     // flattened [to][from][s]
@@ -195,6 +204,11 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
                           int32_t* obs, float* reward, uint8_t* done, uint16_t* act_buf, uint8_t* fb_buf, int k_cap, void* stream);
 int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream);
 int gw_launch_delivered_sfx(const GwState& st, uint32_t* out, void* stream);
+int gw_launch_step_dyn(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
+                       int32_t* obs, float* reward, uint8_t* done, void* stream);
+int gw_launch_init_dyn(const GwState& st, const GwDevConst& cst, double thermal, void* stream);
+int gw_launch_set_position(const GwState& st, const GwDevConst& cst, int radio, const double* xs, const double* ys,
+                           const double* all_pos, const uint8_t* mask, void* stream);
 
 int gw_launch_pack_feedback(int64_t count, int center, int pv, const int32_t* obs, const float* reward, const uint8_t* done,
                             uint8_t* packed, uint32_t* bad, void* stream);

@@ -113,8 +113,12 @@ int gw_build_tables(const gw_config& cfg, GwHostTables& t, char* msg, size_t msg
                     if (memcmp(&t.state_val[j][k], (const void*)&b, sizeof(double)) == 0) { idx = k; break; }
                 if (idx < 0) {
                     if (n == GW_MAX_NSTATES) {
+                        // the (+p, -p) residue of this radio does not close into a small set (it drifts by an ulp per
+                        // packet): no state machine for this geometry -- the live-PHY kernel carries the f64 itself
                         snprintf(msg, msglen, "rx-power state closure of radio %d exceeds %d states", j, GW_MAX_NSTATES);
-                        return GW_EUNSUPPORTED;
+                        t.overflow = 1;
+                        for (int r = 0; r < R; ++r) if (t.nstates[r] == 0) t.nstates[r] = 1;
+                        return GW_OK;
                     }
                     idx = n;
                     t.state_val[j][n++] = b;

@@ -76,6 +76,9 @@ class VecCounterTrafficEnv(BaseEnv):
             AttenuationModelFactory.setCustomModels / JoinedAttenuationModel, physical.py:402-498), reduced to what they
             amount to with static geometry: ``{(a, b): dB}`` added to the free-space term of the pair (radio index
             ``num_devices`` is the RRM), or a callable ``(a, b, pos_a, pos_b) -> dB`` evaluated for every pair.
+        per_env_geometry: positions per ENVIRONMENT (default queue mode): every env starts with the layout above and
+            ``set_position`` / ``set_positions`` move radios between steps (the reference's ``Position.set``,
+            devices/core.py:52-86); link powers are then kept per env and rebuilt on the GPU.
         counter_traffic / peer_receive / float_duration (explicit_queue only): switch the
             counter processes off so that packets come from enqueue() only; keep every sender MAC in receive
             mode (get_state("peer_received") counts what it hands up); pass assignment durations as floats
@@ -91,7 +94,7 @@ class VecCounterTrafficEnv(BaseEnv):
                  multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
                  reuse_outputs=True, explicit_queue=False, counter_bound=None, interpreter=None,
                  counter_traffic=True, peer_receive=False, float_duration=False, extra_attenuation=None,
-                 start_time=None):
+                 start_time=None, per_env_geometry=False):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -139,6 +142,8 @@ class VecCounterTrafficEnv(BaseEnv):
             cfg.flags |= nat.CFG_PEER_RECEIVE
         if float_duration:
             cfg.flags |= nat.CFG_FLOAT_DURATION
+        if per_env_geometry:
+            cfg.flags |= nat.CFG_PER_ENV_GEOMETRY
         if counter_bound is not None:          # tests: reach counter saturation quickly
             cfg.counter_bound = int(counter_bound)
             self.COUNTER_BOUND = int(counter_bound)
@@ -328,6 +333,32 @@ class VecCounterTrafficEnv(BaseEnv):
                                                  reward.data_ptr(), done.data_ptr(), self._stream()))
         return obs, reward, done
 
+    def set_position(self, radio, x, y, mask=None):
+        """``device.position.set(x, y)`` on radio ``radio`` (0..D-1 senders, D = the RRM) of every env (or of the envs
+        selected by ``mask``), between two steps (devices/core.py:77-86): float64[N] tensors/arrays or scalars."""
+        torch = _torch()
+        xs = torch.as_tensor(x, dtype=torch.float64, device=self.device).expand(self.num_envs).contiguous()
+        ys = torch.as_tensor(y, dtype=torch.float64, device=self.device).expand(self.num_envs).contiguous()
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            assert m.shape == (self.num_envs,)
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_set_position(self._h, int(radio), xs.data_ptr(), ys.data_ptr(),
+                                              m.data_ptr() if m is not None else None, self._stream()))
+
+    def set_positions(self, positions, mask=None):
+        """Positions of every radio of every env at once: float64[N][D+1][2] (row D = the RRM)."""
+        torch = _torch()
+        pos = torch.as_tensor(positions, dtype=torch.float64, device=self.device).contiguous()
+        assert pos.shape == (self.num_envs, self.num_devices + 1, 2)
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            assert m.shape == (self.num_envs,)
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_set_positions(self._h, pos.data_ptr(), m.data_ptr() if m is not None else None, self._stream()))
+
     def enqueue(self, device, payload_bytes):
         """SimpleNetworkDevice.send(data, dest) on sender `device` of every env (networking/devices.py:84-86):
         payload_bytes is an int or an int32[N] tensor/array; negative entries enqueue nothing."""
@@ -343,6 +374,7 @@ class VecCounterTrafficEnv(BaseEnv):
         "queue": (np.uint32, lambda D, R: (D, nat.QUEUE_CAP)),
         "received": (np.int32, lambda D, R: (D,)), "latest_diff": (np.int32, lambda D, R: ()),
         "last_abs": (np.int32, lambda D, R: ()), "rx_power": (np.float64, lambda D, R: (R,)),
+        "pos": (np.float64, lambda D, R: (R, 2)), "link_power": (np.float64, lambda D, R: (R, R)),
         "flags": (np.uint32, lambda D, R: ()), "n_tx": (np.uint64, lambda D, R: ()),
         "n_delivered": (np.uint64, lambda D, R: ()), "n_appended": (np.uint64, lambda D, R: ()),
         "n_popped": (np.uint64, lambda D, R: ()), "n_dropped": (np.uint64, lambda D, R: ()),

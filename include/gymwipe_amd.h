@@ -27,6 +27,8 @@
  *                        -> SimpleRrmDevice.assignFrequencyBand   networking/devices.py:178-203
  *                        -> SimMan.runSimulation(eProcessed)      simtools.py:77-88
  *                        -> Interpreter.getFeedback               envs/core.py:142-153
+ *   gw_set_position(s) Position.set -> PositionalAttenuationModel -> FsplAttenuation   devices/core.py:52-86, physical.py:380-386,
+ *                      attenuation_models.py:28-36
  *   gw_received        CounterTrafficInterpreter.receivedValues / getInfo   counter_traffic.py:72,109-112
  *   gw_get_state       attribute reads the reference's tests perform: SimMan.now, sender.counter,
  *                      sender._mac._packetQueue, phy._receivedPower
@@ -124,6 +126,10 @@ typedef struct gw_config {
 #define GW_CFG_FLOAT_DURATION 16            /* the assignment duration is passed as a float (test_stack.py:197):
                                                the announcement payload is len(str(float(slots))) bytes */
 
+#define GW_CFG_PER_ENV_GEOMETRY 32          /* positions per ENVIRONMENT (default queue mode): every env starts with cfg.pos and
+                                               gw_set_position(s) moves radios between steps -- Position.set,
+                                               devices/core.py:52-86; link powers per env, rebuilt on the device (ct_step_dyn.hip) */
+
 typedef struct gw_stats {                   /* totals since gw_create, over all envs */
     uint64_t steps;                         /* env-steps executed */
     uint64_t transmissions;                 /* announcements + data packets */
@@ -180,6 +186,14 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
  * packets of the assigned sender the RRM sniffed (networking/devices.py:163-168). */
 int gw_delivered(gw_env* env, uint32_t* out_dev, void* stream);
 
+/* Position.set(x, y) on radio `radio` (0..D-1 senders, D = the RRM) of every env with mask_dev == NULL or mask_dev[e] != 0,
+ * at the envs' current time, i.e. between two env.step() calls (devices/core.py:77-86); the attenuation of every link of
+ * that radio is recomputed (physical.py:380-386, attenuation_models.py:28-36) with the device libm.  x_dev / y_dev:
+ * double[N] device pointers.  Needs GW_CFG_PER_ENV_GEOMETRY. */
+int gw_set_position(gw_env* env, int32_t radio, const double* x_dev, const double* y_dev, const uint8_t* mask_dev, void* stream);
+/* the same for every radio at once: pos_dev is double[N][R][2] (device pointer), R = num_devices + 1 */
+int gw_set_positions(gw_env* env, const double* pos_dev, const uint8_t* mask_dev, void* stream);
+
 /* receivedValues of every env: int32[N][D] (row-major), device pointer. */
 int gw_received(gw_env* env, int32_t* out_dev, void* stream);
 
@@ -187,7 +201,8 @@ int gw_received(gw_env* env, int32_t* out_dev, void* stream);
  *   "now" f64[N] | "wake" f64[N][D] | "counter" u32[N][D] | "qlen" i32[N][D]
  *   "queue" u32[N][D][GW_QUEUE_CAP] (logical order from the head, zero padded)
  *   "received" i32[N][D] | "latest_diff" i32[N] | "last_abs" i32[N] | "rx_power" f64[N][R]
- *   "flags" u32[N] | "n_tx","n_delivered","n_appended","n_popped","n_dropped" u64[N] (per-env event counts) */
+ *   "flags" u32[N] | "n_tx","n_delivered","n_appended","n_popped","n_dropped" u64[N] (per-env event counts)
+ *   GW_CFG_PER_ENV_GEOMETRY: "pos" f64[N][R][2] | "link_power" f64[N][R][R] (mW, from -> to) */
 int gw_get_state(gw_env* env, const char* field, void* dst_host, size_t bytes);
 
 int gw_stats_read(gw_env* env, gw_stats* out);          /* synchronises the device */

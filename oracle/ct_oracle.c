@@ -141,6 +141,35 @@ int cto_config_default(cto_config* c, int D)
     return 0;
 }
 
+/* attenuation and received power of every link from the current positions (attenuation_models.py:28-36,
+ * physical.py:402-457 joined models, simple_stack.py:111) */
+static void build_links(cto_vec* v)
+{
+    const cto_config* cfg = &v->cfg;
+    const int R = v->R;
+    for (int a = 0; a < R; ++a)
+        for (int b = 0; b < R; ++b) {
+            if (a == b) { v->att[a][b] = 0; v->prx[a][b] = 0; continue; }
+            v->att[a][b] = fspl_db(cfg, a, b);
+            if (cfg->extra_att_db[a][b] != 0.0) {            /* physical.py:457: sum() over [FSPL, custom models] */
+                volatile double joined = 0.0 + v->att[a][b];
+                joined = joined + cfg->extra_att_db[a][b];
+                v->att[a][b] = joined;
+            }
+            v->prx[a][b] = pow(10.0, (cfg->tx_power_dbm - v->att[a][b]) / 10);
+        }
+}
+
+/* Position.set between two steps (devices/core.py:77-86): the links of the moved radio get new attenuations
+ * (physical.py:380-386); nothing is on the air at a step boundary, so no reception is touched (simple_stack.py:119-128) */
+void cto_set_position(cto_vec* v, int radio, double x, double y)
+{
+    if (!v || radio < 0 || radio >= v->R) return;
+    v->cfg.pos[radio][0] = x;
+    v->cfg.pos[radio][1] = y;
+    build_links(v);
+}
+
 cto_vec* cto_create(const cto_config* cfg, int64_t n)
 {
     if (!cfg || n <= 0 || cfg->num_devices < 2 || cfg->num_devices > CTO_MAX_DEV) return NULL;
@@ -155,17 +184,7 @@ cto_vec* cto_create(const cto_config* cfg, int64_t n)
     v->thermal = 1.38e-23 * (cfg->temperature_c + 273.15) * cfg->bandwidth * 1000;
     v->data_rate = cfg->code_rate * cfg->bit_rate;
     v->coded_factor = 2 - cfg->code_rate;
-    for (int a = 0; a < R; ++a)
-        for (int b = 0; b < R; ++b) {
-            if (a == b) { v->att[a][b] = 0; v->prx[a][b] = 0; continue; }
-            v->att[a][b] = fspl_db(cfg, a, b);
-            if (cfg->extra_att_db[a][b] != 0.0) {            /* physical.py:457: sum() over [FSPL, custom models] */
-                volatile double joined = 0.0 + v->att[a][b];
-                joined = joined + cfg->extra_att_db[a][b];
-                v->att[a][b] = joined;
-            }
-            v->prx[a][b] = pow(10.0, (cfg->tx_power_dbm - v->att[a][b]) / 10);
-        }
+    build_links(v);
 #define ALLOC(p, cnt) do { (p) = calloc((size_t)(cnt), sizeof *(p)); if (!(p)) { cto_destroy(v); return NULL; } } while (0)
     ALLOC(v->now, n);       ALLOC(v->wake, n * D);    ALLOC(v->counter, n * D);
     ALLOC(v->q, n * D * CTO_QUEUE_CAP);

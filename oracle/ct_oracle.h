@@ -59,6 +59,8 @@ int  cto_config_default(cto_config* cfg, int num_devices);
 
 cto_vec* cto_create(const cto_config* cfg, int64_t num_envs);
 void cto_destroy(cto_vec* v);
+/* Position.set(x, y) on one radio of EVERY env of the handle, between two steps (devices/core.py:77-86) */
+void cto_set_position(cto_vec* v, int radio, double x, double y);
 
 /* reset(): counters <- 0, interpreter <- 0, NO time rewind (counter_traffic.py:135-144).
  * mask may be NULL (all envs).  obs_out may be NULL. */

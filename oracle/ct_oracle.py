@@ -71,6 +71,8 @@ def lib():
         L.cto_create.restype = C.c_void_p
         L.cto_destroy.argtypes = [C.c_void_p]
         L.cto_destroy.restype = None
+        L.cto_set_position.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        L.cto_set_position.restype = None
         L.cto_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cto_reset.restype = None
         L.cto_step.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
@@ -155,6 +157,10 @@ class CtOracle:
             self.close()
         except Exception:
             pass
+
+    def set_position(self, radio, x, y):
+        """Position.set on one radio of every env of this handle (between steps)."""
+        lib().cto_set_position(self._h, int(radio), float(x), float(y))
 
     def reset(self, mask=None):
         obs = np.empty(self.n, np.int32)

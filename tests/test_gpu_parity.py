@@ -273,11 +273,7 @@ def test_parity_on_random_geometries(seed):
     mult = [int(m) for m in rng.integers(1, 5, D)]
     rrm = (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)))
     N, K = 512, 48
-    try:
-        env, orc = _mk(N, D, positions=pos, multiplicity=mult, rrm_position=rrm)
-    except RuntimeError as exc:                   # > 16 noise states for this geometry: refused loudly, not mis-modelled
-        assert "state closure" in str(exc)
-        pytest.skip(str(exc))
+    env, orc = _mk(N, D, positions=pos, multiplicity=mult, rrm_position=rrm)   # any layout: no finite noise-state set -> live-PHY kernel
     dev, dur = action_stream(seed, K, N, D)
     _run(env, orc, dev, dur, reset_every=17)
 

@@ -146,24 +146,52 @@ __global__ __launch_bounds__(256) void expand_feedback_kernel(uint32_t N, int K,
     }
 }
 
+// Per-lane arrays of the rollout kernel.  DT > 0: registers (every loop over senders is unrolled, indices are static);
+// DT == 0 (any sender count): one LDS column per lane -- the same source lines index either.
+template <int N>
+struct RegArr {
+    uint32_t v[N];
+    __device__ __forceinline__ uint32_t& operator[](int i) { return v[i]; }
+};
+struct LdsArr {
+    uint32_t* p;                                         // this lane's column: element i at p[i * 64]
+    __device__ __forceinline__ uint32_t& operator[](int i) const { return p[i << 6]; }
+};
+template <int N> struct ConstRegArr {
+    uint32_t v[N];
+    __device__ __forceinline__ uint32_t operator[](int i) const { return v[i]; }
+};
+struct ConstMemArr {                                     // wave-uniform index into the handle's constants in device memory
+    const void* p; int shift16;
+    __device__ __forceinline__ uint32_t operator[](int i) const
+    {
+        return shift16 ? (uint32_t)reinterpret_cast<const uint16_t*>(p)[i] : reinterpret_cast<const uint32_t*>(p)[i];
+    }
+};
+template <bool GEN, int N> struct ArrSel { typedef RegArr<N> rw; typedef ConstRegArr<N> ro; };
+template <int N> struct ArrSel<true, N> { typedef LdsArr rw; typedef ConstMemArr ro; };
+
 template <int DT>
 __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevConst c, int K, int Kp,
                                                             const uint16_t* __restrict__ actions,
                                                             uint8_t* __restrict__ feedback)
 {
-    constexpr int NWC = (2 * DT + 1 + 15) / 16;
+    constexpr bool GEN = DT == 0;                        // any sender count: per-lane arrays in LDS, launched with 64 threads
+    constexpr int DM = GEN ? GW_MAX_DEVICES : DT;        // capacity
+    constexpr int NWC = (2 * DM + 1 + 15) / 16;
     constexpr int S = GW_MAX_NSTATES;
-    constexpr int D = DT, R = DT + 1, RRM = DT;
+    const int D = GEN ? c.D : DT, R = D + 1, RRM = D;
     const uint32_t N = (uint32_t)st.N;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
 
     // ---- lookup tables -> LDS ----------------------------------------------------------------------
-    constexpr int TRANS_B = (R * R * S + 15) / 16 * 16;
+    constexpr int TRANS_B = ((DM + 1) * (DM + 1) * S + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_trans[TRANS_B];
-    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DT * S];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DT * S];
+    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DM * S];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DM * S];
+    __shared__ uint32_t s_cols[GEN ? (3 * DM + 1) * 64 : 1];     // GEN: len[D], tb[D], sta[R] columns per lane
     {
-        const int n_tr = TRANS_B >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;
+        const int n_tr = (R * R * S + 15) >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;
         for (int i = threadIdx.x; i < n_tr; i += blockDim.x) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)i << 4)) = ld<uint4>(st.trans, (uint32_t)i << 4);
         for (int i = threadIdx.x; i < n_be; i += blockDim.x) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)i << 4)) = ld<uint4>(st.ber2, (uint32_t)i << 4);
         for (int i = threadIdx.x; i < n_cl; i += blockDim.x) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)i << 4)) = ld<uint4>(st.cls2, (uint32_t)i << 4);
@@ -172,7 +200,8 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     if (e >= N) return;
 
     // ---- state -> registers --------------------------------------------------------------------------
-    const uint32_t o16 = e << 4, o32 = e << 5, oq = e * (16u * NWC);
+    const uint32_t RB = GEN ? (uint32_t)st.RB : 16u * NWC;
+    const uint32_t o16 = e << 4, o32 = e << 5, oq = e * RB;
     const uint4 ip = ld<uint4>(st.ip, o16);
     const double2 tw = ld<double2>(st.tw, o16);
     const uint4 tk = ld<uint4>(st.tk, o16);
@@ -181,15 +210,21 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     // for every store issued before it
     asm volatile("" : "+v"(sa0.x), "+v"(sa0.y), "+v"(sa0.z), "+v"(sa0.w));
     asm volatile("" : "+v"(sa1.x), "+v"(sa1.y), "+v"(sa1.z), "+v"(sa1.w));
-    uint32_t len[DT], sta[R];
-    {
+    typename ArrSel<GEN, DM>::rw len, tb;
+    typename ArrSel<GEN, DM + 1>::rw sta;
+    if constexpr (GEN) {
+        uint32_t* col = s_cols + (threadIdx.x & 63);
+        len.p = col; tb.p = col + DM * 64; sta.p = col + 2 * DM * 64;
+        for (int i = 0; i < D; ++i) len[i] = st.qb[oq + (uint32_t)i];
+        for (int j = 0; j < R; ++j) sta[j] = st.qb[oq + (uint32_t)(D + j)];
+    } else {
         uint4 qw[NWC];
 #pragma unroll
         for (int w = 0; w < NWC; ++w) qw[w] = ld<uint4>(st.qb, oq + 16u * w);
 #pragma unroll
         for (int i = 0; i < DT; ++i) len[i] = (word_of(qw[i >> 4], (i >> 2) & 3) >> ((i & 3) * 8)) & 0xffu;
 #pragma unroll
-        for (int j = 0; j < R; ++j) sta[j] = (word_of(qw[(DT + j) >> 4], ((DT + j) >> 2) & 3) >> (((DT + j) & 3) * 8)) & 0xffu;
+        for (int j = 0; j < DT + 1; ++j) sta[j] = (word_of(qw[(DT + j) >> 4], ((DT + j) >> 2) & 3) >> (((DT + j) & 3) * 8)) & 0xffu;
     }
     double now = tw.x, wake = tw.y;
     uint32_t tau = tk.x;
@@ -208,9 +243,13 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     const bool fast_ticks = c.fast_ticks != 0;
     const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
     const int mh = c.mac_hdr, pv = c.payload_value;
-    uint32_t mult[DT], term[DT];
+    typename ArrSel<GEN, DM>::ro mult, term, inv16;
+    if constexpr (GEN) {
+        mult.p = st.cst->mult; mult.shift16 = 0; term.p = st.cst->term; term.shift16 = 1; inv16.p = st.cst->inv16; inv16.shift16 = 0;
+    } else {
 #pragma unroll
-    for (int i = 0; i < DT; ++i) { mult[i] = (uint32_t)c.mult[i]; term[i] = c.term[i]; }
+        for (int i = 0; i < DT; ++i) { mult.v[i] = (uint32_t)c.mult[i]; term.v[i] = c.term[i]; inv16.v[i] = c.inv16[i]; }
+    }
 
     Tally kt = {0, 0, 0, 0, 0};
     uint32_t k_steps = 0, k_bad = 0, fl = 0;
@@ -226,9 +265,8 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     bool finish = false;            // the current step is over: close it at the top of the next iteration
     int d = 0;                      // addressed sender of the current step
     uint32_t len_d = 0, mult_d = 0, inv16_d = 65536u;
-    uint32_t tb[DT];
 #pragma unroll
-    for (int i = 0; i < DT; ++i) tb[i] = tau;
+    for (int i = 0; i < D; ++i) tb[i] = tau;
     uint32_t n_data = 0, s_r_run = 0;
     double cur = now, stopw = 0.0, t_end = 0.0;
     bool cls_valid = false;
@@ -288,13 +326,13 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             // the listeners' noise states: nothing to look up once every one of them is terminal
             bool all_term = true;
 #pragma unroll
-            for (int i = 0; i < DT; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
+            for (int i = 0; i < D; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+            for (int i = 0; i < D; ++i)
                 if (i == d) { len[i] = len_d; tb[i] = tau; }
             if (!all_term) {
 #pragma unroll
-                for (int i = 0; i < DT; ++i) {
+                for (int i = 0; i < D; ++i) {
                     if (i == d) continue;
                     uint32_t si = s_trans[(uint32_t)((i * R + RRM) * S) + sta[i]];      // heard the announcement
                     for (uint32_t n = 0; n < n_data; ++n) {                              // ... and d's data
@@ -335,8 +373,8 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             }
             uint32_t l0 = 0, t0 = 0, s_d_old = 0;
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
-                if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = c.inv16[i]; s_d_old = sta[i]; }
+            for (int i = 0; i < D; ++i)
+                if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = inv16[i]; s_d_old = sta[i]; }
             len_d = gw_len_after_ticks(l0, tau - t0, mult_d, kt);          // the addressed queue, up to date
             const int slots = du * c.duration_factor;
             pay_bytes = ndigits(slots);
@@ -344,7 +382,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             cls_valid = now < c.cls_limit;
             const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];   // d after hearing the RRM
 #pragma unroll
-            for (int i = 0; i < DT; ++i) if (i == d) sta[i] = s_d;
+            for (int i = 0; i < D; ++i) if (i == d) sta[i] = s_d;
             s_r_run = sta[RRM];
             n_data = 0;
             stopw = (double)slots * slot;            // become absolute times once t_r is known
@@ -365,7 +403,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
         } else {
             uint32_t s_d_now = 0;
 #pragma unroll
-            for (int i = 0; i < DT; ++i) if (i == d) s_d_now = sta[i];
+            for (int i = 0; i < D; ++i) if (i == d) s_d_now = sta[i];
             ber_x = s_ber[(uint32_t)(d * S) + s_d_now];
             cls_x = s_cls[(uint32_t)(d * S) + s_d_now];
         }
@@ -429,18 +467,21 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
         while (wake <= now) { if (wake == now) fl |= GW_FLAG_TIE; wake = wake + interval; kk++; }
         tau += kk;
 #pragma unroll
-        for (int i = 0; i < DT; ++i) len[i] = gw_len_after_ticks(len[i], tau - tb[i], mult[i], kt);
+        for (int i = 0; i < D; ++i) len[i] = gw_len_after_ticks(len[i], tau - tb[i], mult[i], kt);
     }
 
     // ---- registers -> state --------------------------------------------------------------------------------
-    {
+    if constexpr (GEN) {
+        for (int i = 0; i < D; ++i) st.qb[oq + (uint32_t)i] = (uint8_t)len[i];
+        for (int j = 0; j < R; ++j) st.qb[oq + (uint32_t)(D + j)] = (uint8_t)sta[j];
+    } else {
         uint32_t nb[16 * NWC];
 #pragma unroll
         for (int b = 0; b < 16 * NWC; ++b) nb[b] = 0u;
 #pragma unroll
         for (int i = 0; i < DT; ++i) nb[i] = len[i];
 #pragma unroll
-        for (int j = 0; j < R; ++j) nb[DT + j] = sta[j];
+        for (int j = 0; j < DT + 1; ++j) nb[DT + j] = sta[j];
 #pragma unroll
         for (int w = 0; w < NWC; ++w) {
             const int b = 16 * w;
@@ -489,7 +530,7 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
     case 6:  rc = launch_rollout<6>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 8:  rc = launch_rollout<8>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 16: rc = launch_rollout<16>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    default: return GW_EUNSUPPORTED;
+    default: rc = launch_rollout<0>(st, cst, K, Kp, act_buf, fb_buf, stream); break;   // any other D (5, 7, ..., 32): per-lane arrays in LDS
     }
     if (rc) return rc;
     hipLaunchKernelGGL(expand_feedback_kernel, dim3(g256), dim3(256), 0, (hipStream_t)stream, N, K, Kp, cst.counter_bound,

@@ -497,7 +497,10 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
         const int64_t o = (int64_t)s * N;
         rc = gw_launch_rollout_sfx(env->st, env->cst_host, chunk, device_dev + o, duration_dev + o, obs_dev + o,
                                    reward_dev + o, done_dev + o, env->st.ract, env->st.rfb, env->st.rcap, stream);
-        if (rc == GW_EUNSUPPORTED) break;
+        if (rc == GW_EUNSUPPORTED) {
+            if (getenv("GW_ROLLOUT_STRICT")) return fail(GW_EUNSUPPORTED, "no fused rollout for this handle (GW_ROLLOUT_STRICT is set)");
+            break;                                               // (steps > rollout capacity 0, max_duration > 254)
+        }
         if (rc) return fail(GW_EHIP, "rollout kernel launch failed at step %d", s);
         s += chunk;
     }

@@ -193,12 +193,15 @@ def test_invalid_action_is_flagged_and_env_left_untouched():
         one.step({"device": 0, "duration": 20})
 
 
-@pytest.mark.parametrize("D,N,K", [(2, 2048, 64), (4, 2048, 37), (4, 1024, 150), (16, 512, 48), (5, 256, 20), (4, 1001, 30), (8, 70, 64), (6, 512, 40)])
-def test_fused_rollout_matches_oracle(D, N, K):
+@pytest.mark.parametrize("D,N,K", [(2, 2048, 64), (4, 2048, 37), (4, 1024, 150), (16, 512, 48), (5, 256, 20), (4, 1001, 30), (8, 70, 64), (6, 512, 40),
+                                   (7, 300, 70), (32, 200, 33), (11, 129, 64)])
+def test_fused_rollout_matches_oracle(D, N, K, monkeypatch):
     """gw_rollout: one persistent launch per <= 64 steps (free-running lanes, state in registers)
     must give exactly what K env.step() calls give -- outputs of every step and the final state.
-    (D = 5 has no fused kernel and takes the per-step fallback inside gw_rollout.)"""
+    Every sender count has a fused kernel (D = 5, 7, 11, 32: the any-D instantiation with per-lane arrays in LDS);
+    GW_ROLLOUT_STRICT makes gw_rollout fail rather than fall back to step launches, so this test cannot pass on a fallback."""
     import torch
+    monkeypatch.setenv("GW_ROLLOUT_STRICT", "1")
     env, orc = _mk(N, D)
     dev, dur = action_stream(300 + D + K, K, N, D)
     assert (env.reset().cpu().numpy() == orc.reset()).all()

@@ -190,6 +190,14 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     __shared__ __attribute__((aligned(16))) double  s_ber[2 * DM * S];
     __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DM * S];
     __shared__ uint32_t s_cols[GEN ? (3 * DM + 1) * 64 : 1];     // GEN: len[D], tb[D], sta[R] columns per lane
+    __shared__ uint2 s_mi[GEN ? DM : 1];                 // GEN: {mult, ceil(65536/mult)} and terminal-state masks, indexed by
+    __shared__ uint32_t s_term[GEN ? DM : 1];            //      the lane's own addressed sender
+    if constexpr (GEN) {
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+            s_mi[i] = make_uint2((uint32_t)st.cst->mult[i], st.cst->inv16[i]);
+            s_term[i] = st.cst->term[i];
+        }
+    }
     {
         const int n_tr = (R * R * S + 15) >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;
         for (int i = threadIdx.x; i < n_tr; i += blockDim.x) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)i << 4)) = ld<uint4>(st.trans, (uint32_t)i << 4);
@@ -243,6 +251,10 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     const bool fast_ticks = c.fast_ticks != 0;
     const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
     const int mh = c.mac_hdr, pv = c.payload_value;
+    uint32_t live_mask = 0u;                             // any-D kernel: bit i = sender i is in a non-terminal noise state
+    if constexpr (GEN) {
+        for (int i = 0; i < D; ++i) live_mask |= ((s_term[i] >> sta[i]) & 1u) ? 0u : (1u << i);
+    }
     typename ArrSel<GEN, DM>::ro mult, term, inv16;
     if constexpr (GEN) {
         mult.p = st.cst->mult; mult.shift16 = 0; term.p = st.cst->term; term.shift16 = 1; inv16.p = st.cst->inv16; inv16.shift16 = 0;
@@ -325,11 +337,18 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             }
             // the listeners' noise states: nothing to look up once every one of them is terminal
             bool all_term = true;
+            if constexpr (GEN) {
+                // any-D kernel: which senders sit in a non-terminal noise state is kept as a bit mask per lane, so the
+                // common case (everyone terminal) costs no pass over the senders
+                all_term = (live_mask & ~(1u << d)) == 0u;
+                len[d] = len_d; tb[d] = tau;
+            } else {
 #pragma unroll
-            for (int i = 0; i < D; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
+                for (int i = 0; i < D; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
 #pragma unroll
-            for (int i = 0; i < D; ++i)
-                if (i == d) { len[i] = len_d; tb[i] = tau; }
+                for (int i = 0; i < D; ++i)
+                    if (i == d) { len[i] = len_d; tb[i] = tau; }
+            }
             if (!all_term) {
 #pragma unroll
                 for (int i = 0; i < D; ++i) {
@@ -341,6 +360,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
                         si = s2;
                     }
                     sta[i] = si;
+                    if constexpr (GEN) live_mask = ((term[i] >> si) & 1u) ? (live_mask & ~(1u << i)) : (live_mask | (1u << i));
                 }
             }
             sta[RRM] = s_r_run;
@@ -372,9 +392,14 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
                 continue;
             }
             uint32_t l0 = 0, t0 = 0, s_d_old = 0;
+            if constexpr (GEN) {
+                l0 = len[d]; t0 = tb[d]; s_d_old = sta[d];
+                mult_d = s_mi[d].x; inv16_d = s_mi[d].y;
+            } else {
 #pragma unroll
-            for (int i = 0; i < D; ++i)
-                if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = inv16[i]; s_d_old = sta[i]; }
+                for (int i = 0; i < D; ++i)
+                    if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = inv16[i]; s_d_old = sta[i]; }
+            }
             len_d = gw_len_after_ticks(l0, tau - t0, mult_d, kt);          // the addressed queue, up to date
             const int slots = du * c.duration_factor;
             pay_bytes = ndigits(slots);
@@ -382,7 +407,11 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             cls_valid = now < c.cls_limit;
             const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];   // d after hearing the RRM
 #pragma unroll
-            for (int i = 0; i < D; ++i) if (i == d) sta[i] = s_d;
+            for (int i = 0; i < (GEN ? 0 : D); ++i) if (i == d) sta[i] = s_d;
+            if constexpr (GEN) {
+                sta[d] = s_d;
+                live_mask = ((s_term[d] >> s_d) & 1u) ? (live_mask & ~(1u << d)) : (live_mask | (1u << d));
+            }
             s_r_run = sta[RRM];
             n_data = 0;
             stopw = (double)slots * slot;            // become absolute times once t_r is known
@@ -403,7 +432,8 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
         } else {
             uint32_t s_d_now = 0;
 #pragma unroll
-            for (int i = 0; i < D; ++i) if (i == d) s_d_now = sta[i];
+            for (int i = 0; i < (GEN ? 0 : D); ++i) if (i == d) s_d_now = sta[i];
+            if constexpr (GEN) s_d_now = sta[d];
             ber_x = s_ber[(uint32_t)(d * S) + s_d_now];
             cls_x = s_cls[(uint32_t)(d * S) + s_d_now];
         }
@@ -530,6 +560,7 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
     case 6:  rc = launch_rollout<6>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 8:  rc = launch_rollout<8>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     case 16: rc = launch_rollout<16>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
+    case 32: rc = launch_rollout<32>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
     default: rc = launch_rollout<0>(st, cst, K, Kp, act_buf, fb_buf, stream); break;   // any other D (5, 7, ..., 32): per-lane arrays in LDS
     }
     if (rc) return rc;

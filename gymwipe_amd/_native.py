@@ -28,7 +28,7 @@ CFG_PER_ENV_GEOMETRY = 32
 EXPORTS = (
     "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
     "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_set_position", "gw_set_positions", "gw_received", "gw_delivered", "gw_enqueue", "gw_pack_feedback", "gw_unpack_feedback", "gw_get_state",
-    "gw_stats_read", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue", "gw_selftest_runq",
+    "gw_stats_read", "gw_clear_flags", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue", "gw_selftest_runq",
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
     "gw_plant_state_ptr", "gw_plant_get_state", "gw_plant_feedback", "gw_plant_update_feedback", "gw_now_ptr", "gw_pendulum_step",
@@ -178,6 +178,7 @@ def lib():
     L.gw_selftest_queue.argtypes, L.gw_selftest_queue.restype = [C.c_uint64, i32, i32, i32], C.c_int
     L.gw_set_position.argtypes, L.gw_set_position.restype = [vp, i32, vp, vp, vp, vp], C.c_int
     L.gw_set_positions.argtypes, L.gw_set_positions.restype = [vp, vp, vp, vp], C.c_int
+    L.gw_clear_flags.argtypes, L.gw_clear_flags.restype = [vp, vp], C.c_int
     L.gw_selftest_runq.argtypes, L.gw_selftest_runq.restype = [C.c_uint64, i32, i32, i32], C.c_int
     L.gw_selftest_fastmath.argtypes = [C.POINTER(Config), C.POINTER(i32)]
     L.gw_selftest_fastmath.restype = C.c_int

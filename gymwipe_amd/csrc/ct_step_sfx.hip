@@ -634,6 +634,17 @@ __global__ void ct_delivered_sfx_kernel(GwState st, uint32_t* __restrict__ out)
     if (e < (uint32_t)st.N) out[e] = st.sa[(size_t)e * 8 + 2];
 }
 
+// the sticky per-env GW_FLAG_* bits (and, in the explicit-queue mode, their per-wave OR) back to zero
+__global__ void ct_clear_flags_kernel(GwState st)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < st.N) {
+        if (st.sa) st.sa[(size_t)e * 8 + 7] = 0u;
+        if (st.flags) st.flags[e] = 0u;
+    }
+    if (st.totals && e < st.n_slots) st.totals[(size_t)e * GW_T_COUNT + GW_T_FLAGS] = 0ull;
+}
+
 template <int DT>
 int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
            int32_t* obs, float* reward, uint8_t* done, void* stream)
@@ -697,5 +708,12 @@ int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantD
 {
     const unsigned grid = (unsigned)((st.N + 63) / 64);
     hipLaunchKernelGGL(pend_step_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
+    return ok_or_ehip();
+}
+
+int gw_launch_clear_flags(const GwState& st, void* stream)
+{
+    const int64_t n = st.N > st.n_slots ? st.N : st.n_slots;
+    hipLaunchKernelGGL(ct_clear_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, st);
     return ok_or_ehip();
 }

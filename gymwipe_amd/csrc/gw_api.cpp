@@ -114,6 +114,13 @@ int validate(const gw_config& c)
         for (int i = 0; i < c.num_devices; ++i)
             if (c.mult[i] > GW_MAX_MULT)
                 return fail(GW_EUNSUPPORTED, "mult[%d] > %d needs GW_CFG_EXPLICIT_QUEUE", i, GW_MAX_MULT);
+        // the default kernels address every per-env record with 32-bit byte offsets: e << 5 for the 32-byte counter record,
+        // e * RB for the byte record (RB = 16 * ceil((2D + 1) / 16): 48 at D = 16, 80 at D = 32)
+        const int64_t rb = 16 * ((2 * (int64_t)c.num_devices + 1 + 15) / 16);
+        const int64_t cap = 0xffffffffll / (rb > 32 ? rb : 32);
+        if (c.num_envs > cap)
+            return fail(GW_EUNSUPPORTED, "num_envs %lld exceeds %lld, the most the default mode addresses at %d devices "
+                        "(32-bit record offsets); use several handles", (long long)c.num_envs, (long long)cap, c.num_devices);
     }
     if ((c.flags & (GW_CFG_NO_COUNTER_TRAFFIC | GW_CFG_PEER_RECEIVE | GW_CFG_FLOAT_DURATION)) && !(c.flags & GW_CFG_EXPLICIT_QUEUE))
         return fail(GW_EUNSUPPORTED, "GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION need GW_CFG_EXPLICIT_QUEUE");
@@ -353,7 +360,6 @@ int gw_create(const gw_config* cfg, gw_env** out)
         TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
         TRY_ALLOC(st.rxs, N * R);
     } else {
-        if (N > (1ll << 27)) { gw_destroy(env); return fail(GW_EUNSUPPORTED, "num_envs > 2^27 needs GW_CFG_EXPLICIT_QUEUE"); }
         st.RB = 16 * ((2 * D + 1 + 15) / 16);
         TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);     TRY_ALLOC(st.ip, N * 4);
         TRY_ALLOC(st.qb, N * st.RB);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
@@ -599,6 +605,15 @@ int gw_received(gw_env* env, int32_t* out_dev, void* stream)
     if (rc) return rc;
     if (env->st.tk ? gw_launch_received_sfx(env->st, out_dev, stream) : gw_launch_received(env->st, out_dev, stream))
         return fail(GW_EHIP, "received kernel launch failed");
+    return GW_OK;
+}
+
+int gw_clear_flags(gw_env* env, void* stream)
+{
+    if (!env) return fail(GW_EINVAL, "env is NULL");
+    int rc = select_device(env);
+    if (rc) return rc;
+    if (gw_launch_clear_flags(env->st, stream)) return fail(GW_EHIP, "clear_flags kernel launch failed");
     return GW_OK;
 }
 

@@ -94,7 +94,7 @@ class VecCounterTrafficEnv(BaseEnv):
                  multiplicity=None, dest=None, rrm_position=None, per_env_stats=False,
                  reuse_outputs=True, explicit_queue=False, counter_bound=None, interpreter=None,
                  counter_traffic=True, peer_receive=False, float_duration=False, extra_attenuation=None,
-                 start_time=None, per_env_geometry=False):
+                 start_time=None, per_env_geometry=False, counter_interval=None, duration_factor=None):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("gymwipe_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -144,6 +144,11 @@ class VecCounterTrafficEnv(BaseEnv):
             cfg.flags |= nat.CFG_FLOAT_DURATION
         if per_env_geometry:
             cfg.flags |= nat.CFG_PER_ENV_GEOMETRY
+        if counter_interval is not None:       # COUNTER_INTERVAL (counter_traffic.py:31)
+            cfg.counter_interval = float(counter_interval)
+        if duration_factor is not None:        # ASSIGNMENT_DURATION_FACTOR (envs/core.py:27)
+            cfg.duration_factor = int(duration_factor)
+            self.ASSIGNMENT_DURATION_FACTOR = int(duration_factor)
         if counter_bound is not None:          # tests: reach counter saturation quickly
             cfg.counter_bound = int(counter_bound)
             self.COUNTER_BOUND = int(counter_bound)
@@ -408,15 +413,27 @@ class VecCounterTrafficEnv(BaseEnv):
         nat.check(self._L.gw_noise_states(self._h, radio, C.byref(n), vals))
         return [vals[i] for i in range(n.value)]
 
-    def check(self):
-        """Raise if any env hit a condition outside the modelled horizon or got a bad action."""
+    def check(self, strict=False):
+        """Raise if any env hit a condition outside the modelled horizon or got a bad action.  The returned totals carry
+        ``"ties"``: whether an exact f64 time tie was resolved by the insertion-order rule (GW_FLAG_TIE) -- the kernels and
+        the oracle resolve it the same way, but the reference's order there rests on SimPy's event ids; ``strict=True``
+        raises on it too.  Flags are sticky: ``clear_flags()`` resets them so that a later check tells when they arose."""
         st = self.stats()
         fl = st["flags_or"]
+        st["ties"] = bool(fl & nat.FLAG_TIE)
         if fl & nat.FLAG_BADACT:
             raise AssertionError("%d env-step(s) had an action outside the action space" % st["bad_actions"])
         if fl & (nat.FLAG_CARRY | nat.FLAG_REFEXC):
             raise RuntimeError("step horizon not closed in some env (flags 0x%x)" % fl)
+        if strict and st["ties"]:
+            raise RuntimeError("an exact time tie was resolved by the insertion-order rule in some env (GW_FLAG_TIE)")
         return st
+
+    def clear_flags(self):
+        """Zero the sticky per-env GW_FLAG_* words (event counters are untouched)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            nat.check(self._L.gw_clear_flags(self._h, self._stream()))
 
 
 class CounterTrafficEnv(VecCounterTrafficEnv):

@@ -206,6 +206,9 @@ int gw_received(gw_env* env, int32_t* out_dev, void* stream);
 int gw_get_state(gw_env* env, const char* field, void* dst_host, size_t bytes);
 
 int gw_stats_read(gw_env* env, gw_stats* out);          /* synchronises the device */
+/* the sticky per-env flag words back to zero (gw_get_state "flags", gw_stats.flags_or), so that a later check tells
+ * WHEN a condition arose; counters are untouched */
+int gw_clear_flags(gw_env* env, void* stream);
 int gw_state_bytes(gw_env* env, uint64_t* bytes);       /* HBM held by this handle */
 
 /* static link tables (host side, for tests): attenuation dB, rx power mW, thermal mW,

@@ -811,9 +811,10 @@ def default_multiplicity(num_devices):
 
 
 class _Sender(NetDevice):                   # counter_traffic.py:37-61
-    def __init__(self, world, name, x, y, mult, traffic=True):
+    def __init__(self, world, name, x, y, mult, traffic=True, interval=None):
         NetDevice.__init__(self, world, name, x, y)
         self.mult = mult
+        self.interval = COUNTER_INTERVAL if interval is None else interval
         self.counter = 1
         self.dest = None
         self.got = []                       # payloads handed up by a receive-mode MAC
@@ -840,7 +841,7 @@ class _Sender(NetDevice):                   # counter_traffic.py:37-61
                 self.send(Blob(COUNTER_BYTE_LENGTH, self.counter), self.dest)
             if self.counter < COUNTER_BOUND:
                 self.counter += 1
-            yield self.world.sim.timeout(COUNTER_INTERVAL)
+            yield self.world.sim.timeout(self.interval)
 
 
 class _Interp:                              # counter_traffic.py:63-112
@@ -878,7 +879,7 @@ class CounterTrafficModel:
 
     def __init__(self, num_devices=2, positions=None, mult=None, dest=None,
                  rrm_pos=(0.0, 0.0), traffic=True, peer_receive=False,
-                 rx_duration=10, float_duration=False, extra_att=None):
+                 rx_duration=10, float_duration=False, extra_att=None, counter_interval=None):
         """traffic=False: no counter processes, packets come from enqueue();
         peer_receive: every sender MAC is kept in receive mode (SURVEY 8f rank
         2; the reference env never does this); float_duration: the assignment
@@ -891,7 +892,7 @@ class CounterTrafficModel:
         self.world = World()
         self.sim = self.world.sim
         self.senders = [_Sender(self.world, "Sender %d" % (i + 1),
-                                positions[i][0], positions[i][1], mult[i], traffic)
+                                positions[i][0], positions[i][1], mult[i], traffic, counter_interval)
                         for i in range(D)]
         idx2mac = {i: s.mac_addr for i, s in enumerate(self.senders)}
         for i, s in enumerate(self.senders):

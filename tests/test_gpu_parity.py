@@ -656,3 +656,44 @@ def test_create_destroy_does_not_leak_device_memory():
     torch.cuda.synchronize(); gc.collect()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)        # allocator granularity, not a per-cycle leak
+
+
+@pytest.mark.parametrize("explicit", QUEUE_MODES)
+@pytest.mark.parametrize("case", ["tick == window start", "tick == end of a data transmission", "guard slot"])
+def test_ordering_edge_cases_on_the_gpu(case, explicit):
+    """The exact f64 time ties and the guard-slot ending that tests/test_oracle_pinning.py pins between the two oracle
+    layers, through the HIP kernels (step kernels of both queue modes and the fused rollout): same outputs, same state,
+    same GW_FLAG_TIE."""
+    import torch
+    from test_oracle_pinning import tie_intervals
+    from gymwipe_amd import VecCounterTrafficEnv
+    from gymwipe_amd import _native as nat
+    from oracle.ct_oracle import CtOracle, default_config
+    N, D = 256, 2
+    kw, cfg = {}, default_config(D)
+    if case == "guard slot":
+        kw["duration_factor"] = cfg.duration_factor = 2081
+        acts = [(0, 1), (1, 1), (0, 1), (1, 0), (0, 1), (1, 1)]
+    else:
+        kw["counter_interval"] = cfg.counter_interval = tie_intervals()[case]
+        acts = [(0, 19), (1, 7), (0, 3), (1, 19), (0, 0), (1, 12)]
+    env = VecCounterTrafficEnv(N, num_devices=D, per_env_stats=True, explicit_queue=explicit, **kw)
+    fused = None if explicit else VecCounterTrafficEnv(N, num_devices=D, **kw)
+    orc = CtOracle(N, D, config=cfg, nthreads=4)
+    dev = np.array([[a[0]] * N for a in acts], np.int32)
+    dur = np.array([[a[1]] * N for a in acts], np.int32)
+    dev[:, 1::2] = 1 - dev[:, 1::2]                              # every other env addresses the other sender
+    outs = []
+    for k in range(len(acts)):
+        o, r, d, _ = env.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (o.cpu().numpy() == oo).all() and (r.cpu().numpy() == orr).all(), k
+        outs.append((oo, orr))
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where=case)
+    if case == "tick == end of a data transmission":
+        assert (env.get_state("flags") & nat.FLAG_TIE).any()
+    if fused is not None:
+        fo, fr, fd = fused.rollout(torch.from_numpy(dev), torch.from_numpy(dur))
+        for k in range(len(acts)):
+            assert (fo[k].cpu().numpy() == outs[k][0]).all() and (fr[k].cpu().numpy() == outs[k][1]).all(), k
+        assert_state_equal(fused, orc, STATE_FIELDS, where=case + " (rollout)")

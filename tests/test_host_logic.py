@@ -202,7 +202,14 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu(native_lib):
         assert rc in (nat.EINVAL, nat.EUNSUPPORTED), (rc, L.gw_last_error())
         assert word in L.gw_last_error(), L.gw_last_error()
         assert not h.value
+    # 32-bit record offsets of the default kernels: e * RB must fit (RB = 48 B at D = 16, 80 B at D = 32, >= 32 B always)
+    for D, most in ((4, 0xffffffff // 32), (16, 0xffffffff // 48), (32, 0xffffffff // 80)):
+        cfg = nat.default_config(most + 1, D)
+        assert L.gw_create(C.byref(cfg), C.byref(h)) == nat.EUNSUPPORTED and b"32-bit record offsets" in L.gw_last_error()
+        cfg = nat.default_config(most, D)                                   # the bound itself passes validation (host-only entry)
+        assert L.gw_selftest_fastmath(C.byref(cfg), None) >= 0
     # handle-taking entries refuse a NULL handle
+    assert L.gw_clear_flags(None, None) == nat.EINVAL
     assert L.gw_step(None, None, None, None, None, None, None) == nat.EINVAL
     assert L.gw_reset(None, None, None, None) == nat.EINVAL
     assert L.gw_rollout(None, 1, None, None, None, None, None, None) == nat.EINVAL

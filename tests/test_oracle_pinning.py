@@ -234,3 +234,92 @@ def test_oracle_rejects_invalid_actions():
         orc.step([0, 2], [1, 1])                           # counter_traffic.py:147
     with pytest.raises(AssertionError):
         orc.step([0, 1], [20, 1])
+
+
+# ---- ordering edge cases: exact f64 time ties and the guard slot -------------------------------------
+def _event_time(tx):
+    """When a transmission's completion event fires: now + (stop - now) with now = its start (simtools.py:112-116)."""
+    return tx.start + (tx.stop - tx.start)
+
+
+def tie_intervals():
+    """Counter intervals that put the SECOND counter tick (at 0 + interval, exactly) on an event time of the first step
+    {device 0, duration 19} of a fresh env: (a) the window start t_r, (b) the end t_e of the first data transmission.
+    Found on layer 1, whose first step does not depend on the interval up to those times."""
+    import oracle.des_model as dm
+    m = dm.CounterTrafficModel(2)
+    m.step(0, 19)
+    log = m.world.band.log
+    assert log[0].sender is m.rrm.phy or True
+    return {"tick == window start": _event_time(log[0]), "tick == end of a data transmission": _event_time(log[1])}
+
+
+@pytest.mark.parametrize("case", ["tick == window start", "tick == end of a data transmission"])
+def test_exact_time_ties_resolved_identically_by_both_layers(case):
+    """A counter tick falling EXACTLY on the MAC's window start (the MAC's process initialisation is URGENT: it sees the
+    queue before the tick) or on the end of a transmission (the tick is the older event: it goes first).  Layer 1 resolves
+    them by its event heap's (time, priority, insertion id) order, layer 2 by the flattened rule; both must agree on
+    every output and state, and layer 2 must raise GW_FLAG_TIE for the inclusive case."""
+    import oracle.des_model as dm
+    from oracle.ct_oracle import FLAG_TIE
+    interval = tie_intervals()[case]
+    assert 1e-3 < interval < 4e-3
+    py = dm.CounterTrafficModel(2, counter_interval=interval)
+    cfg = default_config(2)
+    cfg.counter_interval = interval
+    co = CtOracle(1, 2, config=cfg)
+    acts = [(0, 19), (1, 7), (0, 3), (1, 19), (0, 0), (1, 12)]
+    for k, (d, du) in enumerate(acts):
+        o, r, dn, _ = py.step(d, du)
+        oc, rc, dc = co.step([d], [du])
+        s = py.snapshot()
+        assert (o, r, dn) == (int(oc[0]), float(rc[0]), bool(dc[0])), k
+        assert s["now"] == co.get("now")[0] and s["qlen"] == co.get("qlen")[0].tolist(), k
+        assert s["counters"] == co.get("counter")[0].tolist() and s["n_tx"] == int(co.get("n_tx")[0]), k
+        q = co.get("queue")[0]
+        for i in range(2):
+            assert s["queues"][i] == q[i][:s["qlen"][i]].tolist(), (i, k)
+        if k == 0:
+            # the tie really happened: the second tick is exactly the event time
+            ev = _event_time(py.world.band.log[0 if case == "tick == window start" else 1])
+            assert ev == interval
+            if case != "tick == window start":
+                assert int(co.get("flags")[0]) & FLAG_TIE
+    assert int(co.get("flags")[0]) & (FLAG_CARRY | FLAG_REFEXC) == 0
+
+
+def _layer1_step_slots(py, device, slots):
+    """CounterTrafficModel.step with an explicit slot count (the assignment duration factor is a module constant there)."""
+    sig = py.rrm.assign(device, slots)
+    py.sim.run(sig.done)
+    return py.interp.feedback()
+
+
+@pytest.mark.parametrize("factor", [2081, 2082])
+def test_transmission_ending_in_the_guard_slot(factor):
+    """A data transmission may END after the window's stop time -- the fit test (simple_stack.py:418-420) is made before
+    the slot alignment adds up to one slot -- but before the step does, because the RRM waits one guard slot more
+    (:557-558).  With the usual 1000-slot duration factor that needs a leftover of less than one slot and practically
+    never happens, so the window is sized for it: a fresh env's first packet (26 B) needs 2080.00005 slots; a window of
+    2081 slots lets it start and end 0.00005 slots after the window's stop, inside the guard slot; 2082 ends it inside the
+    window."""
+    import oracle.des_model as dm
+    py = dm.CounterTrafficModel(2)
+    cfg = default_config(2)
+    cfg.duration_factor = factor
+    co = CtOracle(1, 2, config=cfg)
+    in_guard = 0
+    for k, (d, du) in enumerate([(0, 1), (1, 1), (0, 1), (1, 0), (0, 1)]):
+        n0 = len(py.world.band.log)
+        o, r, dn, _ = _layer1_step_slots(py, d, du * factor)
+        oc, rc, dc = co.step([d], [du])
+        s = py.snapshot()
+        assert (o, r, dn) == (int(oc[0]), float(rc[0]), bool(dc[0])), k
+        assert s["now"] == co.get("now")[0] and s["qlen"] == co.get("qlen")[0].tolist() and s["n_tx"] == int(co.get("n_tx")[0]), k
+        log = py.world.band.log[n0:]
+        stopw = _event_time(log[0]) + (du * factor) * dm.SLOT
+        for tx in log[1:]:
+            assert _event_time(tx) < py.sim.now              # inside the step (else GW_FLAG_CARRY)
+            in_guard += _event_time(tx) >= stopw
+    assert (in_guard > 0) == (factor != 2082), in_guard
+    assert int(co.get("flags")[0]) & (FLAG_CARRY | FLAG_REFEXC) == 0

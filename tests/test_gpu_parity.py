@@ -184,6 +184,13 @@ def test_invalid_action_is_flagged_and_env_left_untouched():
     assert env.stats()["bad_actions"] == 2
     with pytest.raises(AssertionError):
         env.check()
+    # flags are sticky until cleared; clearing tells later checks WHEN something happened, counters stay
+    env.clear_flags()
+    assert not env.get_state("flags").any()
+    st = env.check(strict=True)
+    assert st["bad_actions"] == 2 and st["ties"] is False
+    env.step({"device": torch.from_numpy(dev[4]), "duration": torch.from_numpy(dur[4])})
+    env.check(strict=True)
     # the N = 1 drop-in raises like the reference (counter_traffic.py:147)
     import gymwipe_amd
     one = gymwipe_amd.make("CounterTraffic-v0")

@@ -14,35 +14,40 @@ struct TxTimes { double t_s, t_h, t_e, stop; };
 
 // The three f64 operations of the step that are expensive on the device, each with an exact fast
 // form that gw_create validated for this configuration (gw_fastmath.h) and the plain form otherwise.
-struct StepMath {
+// FAST = every fast form was validated for this handle (the usual case): the flags are compile-time constants and the
+// plain forms' code and the wave-uniform branches around them disappear from the instruction stream.
+template <bool FAST>
+struct StepMathT {
     double slot, inv_slot, fmod_limit, dr, rcp_dr, max_ber;
     int fast_fmod, fast_div, fast_decide;
 
-    __device__ __forceinline__ explicit StepMath(const GwDevConst& c)
+    __device__ __forceinline__ explicit StepMathT(const GwDevConst& c)
         : slot(c.slot), inv_slot(c.inv_slot), fmod_limit(c.fmod_limit), dr(c.data_rate),
-          rcp_dr(c.rcp_data_rate), max_ber(c.max_ber), fast_fmod(c.fast_fmod), fast_div(c.fast_div),
-          fast_decide(c.fast_decide) {}
+          rcp_dr(c.rcp_data_rate), max_ber(c.max_ber), fast_fmod(FAST ? 1 : c.fast_fmod), fast_div(FAST ? 1 : c.fast_div),
+          fast_decide(FAST ? 1 : c.fast_decide) {}
 
     // t % slot                                                       simtools.py:53
     __device__ __forceinline__ double slot_rem(double t) const
     {
-        return (fast_fmod && t < fmod_limit) ? gw_fast_fmod(t, slot, inv_slot) : fmod(t, slot);
+        return ((FAST || fast_fmod) && t < fmod_limit) ? gw_fast_fmod(t, slot, inv_slot) : fmod(t, slot);
     }
     // bits / dataRate                                                 physical.py:244-247, messages.py:67-75
     __device__ __forceinline__ double over_rate(double bits) const
     {
-        return fast_div ? gw_fast_div(bits, dr, rcp_dr) : bits / dr;
+        return (FAST || fast_div) ? gw_fast_div(bits, dr, rcp_dr) : bits / dr;
     }
     // round(errSum)/totalBits <= maxCorrectableBer (banker's rounding) simple_stack.py:269-286
     __device__ __forceinline__ bool decodes(double err, double bits) const
     {
-        return fast_decide ? (4.0 * rint(err) <= bits) : ((rint(err) / bits) <= max_ber);
+        return (FAST || fast_decide) ? (4.0 * rint(err) <= bits) : ((rint(err) / bits) <= max_ber);
     }
 };
+typedef StepMathT<false> StepMath;
 
 // simple_stack.py:204 (next slot; a FULL slot when already aligned) +
 // physical.py:244-279 (durations) + simtools.py:112-116 (events fire at now + (t - now))
-__device__ __forceinline__ TxTimes tx_times(const StepMath& m, double cur, double hd, double pd)
+template <class M>
+__device__ __forceinline__ TxTimes tx_times(const M& m, double cur, double hd, double pd)
 {
     TxTimes x;
     x.t_s = cur + (m.slot - m.slot_rem(cur));
@@ -56,7 +61,8 @@ __device__ __forceinline__ TxTimes tx_times(const StepMath& m, double cur, doubl
 
 // simple_stack.py:214-286 with nothing else on the air: header decision at t_h, then the
 // payload error sum counted twice from the same segment start (:180-188,:223-231,:252).
-__device__ __forceinline__ bool receive(const StepMath& m, double ber, const TxTimes& x, double bit_rate,
+template <class M>
+__device__ __forceinline__ bool receive(const M& m, double ber, const TxTimes& x, double bit_rate,
                                         double hdr_bits, double pay_bits, uint32_t& flags)
 {
     double err = 0.0 + ber * (x.t_h - x.t_s) * bit_rate;
@@ -68,7 +74,8 @@ __device__ __forceinline__ bool receive(const StepMath& m, double ber, const TxT
 }
 
 // Decode outcome of one reception: certain by class (gw_tables.cpp: decode_class), or the exact arithmetic
-__device__ __forceinline__ bool decode(const StepMath& m, uint32_t cls, bool cls_valid, double ber, const TxTimes& x,
+template <class M>
+__device__ __forceinline__ bool decode(const M& m, uint32_t cls, bool cls_valid, double ber, const TxTimes& x,
                                        double br, double hdr_bits, double pay_bits, uint32_t& fl)
 {
     if (!(x.t_e >= x.stop)) fl |= GW_FLAG_REFEXC;        // `not t.completed` -> KeyError in the reference

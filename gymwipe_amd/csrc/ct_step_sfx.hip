@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t word_of(const uint4& w, int i)          // i
 // DT == 0: any device count, the record's bytes are read and written in memory.
 // FEEDBACK: write the CounterTraffic interpreter's (obs, reward, done); the fused pendulum step (below) replaces them by
 // the plant's.  now_out: the env's clock after the step (unchanged for a bad action), live_out: e < N.
-template <int DT, bool FEEDBACK>
+template <int DT, bool FEEDBACK, bool FAST>
 __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevConst& c,
                                                  const int32_t* __restrict__ device,
                                                  const int32_t* __restrict__ duration,
@@ -156,14 +156,14 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     live_out = live;
 
     // ---- constants -> registers, under the shadow of the loads above --------------------------------
-    StepMath m(c);
+    StepMathT<FAST> m(c);
     double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
     double coded_factor = c.coded_factor, cls_limit = c.cls_limit, inv_interval = c.inv_interval;
     int pv = c.payload_value, cbound = c.counter_bound, max_duration = c.max_duration, dfactor = c.duration_factor;
     int mh = c.mac_hdr, base_b = c.mac_hdr + c.net_hdr, idem_i = c.idem_states, fast_ticks = c.fast_ticks;
     __builtin_amdgcn_sched_barrier(0);
     PIN_V(m.slot); PIN_V(m.inv_slot); PIN_V(m.fmod_limit); PIN_V(m.dr); PIN_V(m.rcp_dr); PIN_V(m.max_ber);
-    PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide);
+    if (!FAST) { PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide); }
     PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit); PIN_V(inv_interval);
     PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i); PIN_S(fast_ticks);
     __builtin_amdgcn_sched_barrier(0);
@@ -216,7 +216,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             k_steps = 1;
             const uint32_t bound = (uint32_t)cbound;
             const uint32_t base_bytes = (uint32_t)base_b;
-            const bool idem = idem_i != 0;
+            const bool idem = FAST || idem_i != 0;
 
             uint32_t len_d, s_d_old, s_r_old;
             if (PACKED) {
@@ -309,7 +309,9 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                     const bool b1 = inclusive ? (w1 <= t) : (w1 < t);
                     const bool b2 = inclusive ? (w2 <= t) : (w2 < t);
                     const bool b3 = inclusive ? (w3 <= t) : (w3 < t);
-                    if (inclusive && (wake == t || w1 == t || w2 == t || w3 == t)) fl |= GW_FLAG_TIE;
+                    // the tick times increase, so only the LAST counted one can fall exactly on t
+                    const double last = b3 ? w3 : (b2 ? w2 : (b1 ? w1 : wake));
+                    if (inclusive && b0 && last == t) fl |= GW_FLAG_TIE;
                     const uint32_t n = (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;   // monotone
                     wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
                     kk += n;
@@ -374,7 +376,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 uint32_t nj = 0;
                 double wj = wake;
                 bool tiej = false;
-                if (fast_ticks && gw_tick_jump(wake, t_end, interval, inv_interval, true, &nj, &wj, &tiej)) {
+                if ((FAST || fast_ticks) && gw_tick_jump(wake, t_end, interval, inv_interval, true, &nj, &wj, &tiej)) {
                     wake = wj;
                     tau += nj;
                     if (tiej) fl |= GW_FLAG_TIE;
@@ -462,7 +464,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     STAMP(12);
 }
 
-template <int DT>
+template <int DT, bool FAST>
 __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
                                                          const int32_t* __restrict__ device,
                                                          const int32_t* __restrict__ duration,
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 {
     double now_new;
     bool live;
-    ct_step_sfx_body<DT, true>(st, c, device, duration, obs, reward, done, now_new, live);
+    ct_step_sfx_body<DT, true, FAST>(st, c, device, duration, obs, reward, done, now_new, live);
 }
 
 // ---- BASELINE config 4: env.step() of the pendulum env in ONE launch ------------------------------------------------
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 // components: the wave's 64 plant states go through an LDS transpose and four rounds of 16 envs each.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+template <bool FAST>
 __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c, GwPlantDev p,
                                                        const int32_t* __restrict__ device,
                                                        const int32_t* __restrict__ duration,
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
 
     double now_new;
     bool live;
-    ct_step_sfx_body<2, false>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
+    ct_step_sfx_body<2, false, FAST>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
 
     // substeps to take: n = round((now - last) / dt), nothing if time did not advance
     int n = 0;
@@ -651,8 +654,13 @@ int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, cons
 {
     const unsigned blk = (unsigned)st.block;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
-    hipLaunchKernelGGL((ct_step_sfx_kernel<DT>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                       st, cst, device, duration, obs, reward, done);
+    // every exact fast form validated for this handle (gw_create): the instantiation without their fallbacks
+    if (cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks)
+        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
+                           st, cst, device, duration, obs, reward, done);
+    else
+        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
+                           st, cst, device, duration, obs, reward, done);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
@@ -707,7 +715,10 @@ int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantD
                         int32_t* obs, float* reward, double* angle_deg, void* stream)
 {
     const unsigned grid = (unsigned)((st.N + 63) / 64);
-    hipLaunchKernelGGL(pend_step_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
+    if (cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks)
+        hipLaunchKernelGGL(pend_step_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
+    else
+        hipLaunchKernelGGL(pend_step_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
     return ok_or_ehip();
 }
 

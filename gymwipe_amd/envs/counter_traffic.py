@@ -163,6 +163,8 @@ class VecCounterTrafficEnv(BaseEnv):
             self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
             self._done = torch.empty(n, dtype=torch.uint8, device=self.device)
         self._reuse = bool(reuse_outputs)
+        self._seen = {}                                   # action tensor objects already validated (step())
+        self._dev_index = self.device.index or 0
         self._last = (None, None, None)
         self._custom = interpreter
         if interpreter is not None:                       # a user-supplied Interpreter replaces the fused one
@@ -228,20 +230,31 @@ class VecCounterTrafficEnv(BaseEnv):
         return (type(t) is torch.Tensor and t.dtype is torch.int32 and t.device == self.device
                 and t.dim() == 1 and t.shape[0] == self.num_envs and t.is_contiguous())
 
+    def _checked(self, t, name):
+        """The action tensor, validated (int32, contiguous, right shape, on this env's GPU) or converted.  A tensor OBJECT
+        that passed once is not re-validated (a caller steps with the same pre-staged tensors again and again; dtype, device
+        and shape of a tensor object do not change under ordinary use): one dict probe instead of seven attribute tests."""
+        hit = self._seen.get(id(t))
+        if hit is not None and hit is t:
+            return t
+        if not self._ready(t):
+            return self._as_i32(t, name)
+        if len(self._seen) >= 8192:
+            self._seen.clear()
+        self._seen[id(t)] = t
+        return t
+
     def step(self, action):
         """One env.step() for all N envs: ``action = {"device": int32[N], "duration": int32[N]}``
         (torch tensors on the env's GPU are used in place).  Returns
         ``(obs int32[N], reward float32[N], done uint8[N], info)``; an action outside the action
         space flags its env (``check()`` raises) and leaves that env untouched."""
         torch = _torch()
-        dev, dur = action["device"], action["duration"]
-        if not self._ready(dev):
-            dev = self._as_i32(dev, "device")
-        if not self._ready(dur):
-            dur = self._as_i32(dur, "duration")
+        dev = self._checked(action["device"], "device")
+        dur = self._checked(action["duration"], "duration")
         obs, rew, done = self._outputs()
-        idx = self.device.index or 0
-        if torch.cuda.current_device() == idx:                 # the one-process-per-GPU case: no context switch
+        idx = self._dev_index
+        if torch._C._cuda_getDevice() == idx:                  # the one-process-per-GPU case: no context switch
             rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
                                  done.data_ptr(), torch._C._cuda_getCurrentRawStream(idx))
         else:

@@ -33,3 +33,23 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     for sec in ("fused_rollout", "graph_replay", "steady_state_no_reset"):
         assert "error" not in d[sec], d[sec]
+    assert d["repeats"] >= 1 and d["timed_step_indices_after_reset"][0] == 0 and d["us_per_step"]["min"] <= d["us_per_step"]["max"]
+    assert r["frac"] <= 1.0 or "frac_above_one_because" in r
+    assert r["min_bytes_per_env_step"] == 189 and r["frac_min_bytes"] > 0
+    assert c["by_devices"]["4"]["value"] == c["value"] and c["nproc"] >= c["cores"]
+
+
+@pytest.mark.gpu
+def test_bench_config4_prints_a_contract_line_with_one_launch_per_step():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "20", "--warmup", "5",
+                          "--envs", "4096", "--repeats", "20", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["unit"] == "env-steps/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["repeats"] == 20
+    assert "InvertedPendulum" in d["config"]["workload"] and d["dtype"] == "f64" and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["launches_per_step"] == 1 and r["kernel"] == "pend_step_kernel"
+    assert r["mfma"]["instruction"] == "v_mfma_f64_16x16x4_f64" and 5 < r["mfma"]["plant_substeps_per_env_step"] < 15
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0

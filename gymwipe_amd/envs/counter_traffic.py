@@ -14,6 +14,7 @@ Reference behaviour kept on purpose:
     arguments, :57), so observations are 65534 / 65536 / 65538 and ``done`` never fires
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -235,13 +236,13 @@ class VecCounterTrafficEnv(BaseEnv):
         that passed once is not re-validated (a caller steps with the same pre-staged tensors again and again; dtype, device
         and shape of a tensor object do not change under ordinary use): one dict probe instead of seven attribute tests."""
         hit = self._seen.get(id(t))
-        if hit is not None and hit is t:
+        if hit is not None and hit() is t:
             return t
         if not self._ready(t):
             return self._as_i32(t, name)
         if len(self._seen) >= 8192:
             self._seen.clear()
-        self._seen[id(t)] = t
+        self._seen[id(t)] = weakref.ref(t)                   # weak: the env must not keep a caller's action buffers alive
         return t
 
     def step(self, action):

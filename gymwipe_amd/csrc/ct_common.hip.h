@@ -84,6 +84,29 @@ __device__ __forceinline__ bool decode(const M& m, uint32_t cls, bool cls_valid,
     return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
 }
 
+// ---- live-PHY helpers (ct_step_dyn.hip and the generic kernel's live-PHY instantiation) ----
+// physical.py:25-58 (Eb/N0, Q approximation), :82-98 (dBm helpers), :208-212 (BPSK) with the device libm
+__device__ __forceinline__ double ber_bpsk_dev(double sig_mw, double noise_mw, double ten_log_br)
+{
+    const double s = 10 * log10(sig_mw);
+    const double n = 10 * log10(noise_mw);
+    if (s <= n) return 0.5;
+    const double ratio_db = s - n - ten_log_br;
+    const double ratio = pow(10.0, ratio_db / 10);
+    const double x = sqrt(2 * ratio);
+    const double e = 2.718281828459045;
+    const double sqrt2pi = 2.5066282746310002;
+    return (1 - pow(e, -1.4 * x)) * pow(e, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
+}
+
+// link power from -> to (mW) of env e: per-env table [from][to][N] or the handle's shared [from][to]
+template <bool PER_ENV>
+__device__ __forceinline__ double gw_link(const GwState& st, int R, int from, int to, uint32_t e)
+{
+    if (PER_ENV) return st.prx_env[((size_t)(from * R + to)) * (size_t)st.N + e];
+    return st.prx_tab[from * R + to];
+}
+
 __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value)), v >= 0
 {
     return 1 + (v >= 10) + (v >= 100) + (v >= 1000) + (v >= 10000) + (v >= 100000) + (v >= 1000000) +

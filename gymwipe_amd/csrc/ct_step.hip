@@ -38,7 +38,9 @@ __device__ __forceinline__ GwRec store_q(const GwRunQ& q) { return gw_runq_pack(
 
 // DT > 0: compile-time sender count -- every sender's queue record is loaded up front into registers (the latency
 // overlaps everything else); DT == 0: any sender count, loaded where needed.
-template <int DT, bool PER_ENV_STATS>
+// DYN: the live physical layer (f64 received power per radio in st.rxp, BER on the device, link powers shared or per env)
+// instead of the noise-state bytes -- for layouts without a finite noise-state set; instantiated for DT == 0 only.
+template <int DT, bool PER_ENV_STATS, bool DYN>
 __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                                                         const int32_t* __restrict__ device,
                                                         const int32_t* __restrict__ duration,
@@ -116,13 +118,27 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const double pd_a = m.over_rate((double)(La * 8));
             const TxTimes an = tx_times(m, t_a, hd, pd_a);
             k.tx++;
-            const uint8_t s_d_old = st.rxs[(int64_t)d * N + e];
-            const uint8_t s_d = s_h1[d * S + s_d_old];
-            const double ber_a = s_ber[d * S + s_d];
-            const bool cls_valid = t_a < c.cls_limit;
-            const bool idem = c.idem_states != 0;
-            const bool granted = decode(m, s_cls[d * S + s_d], cls_valid, ber_a, an, br, hdr_bits,
-                                        (double)(La * 8) * c.coded_factor, fl);
+            const bool per_env = DYN && st.prx_env != nullptr;
+            auto lp = [&](int from, int to) -> double {           // link power from -> to, mW
+                return per_env ? gw_link<true>(st, R, from, to, (uint32_t)e) : gw_link<false>(st, R, from, to, (uint32_t)e);
+            };
+            uint8_t s_d_old = 0, s_d = 0;
+            const bool cls_valid = !DYN && t_a < c.cls_limit;
+            const bool idem = !DYN && c.idem_states != 0;
+            bool granted;
+            if (DYN) {                                           // simple_stack.py:82 (+p), :166-167 (noise = received - signal), :154 (-p)
+                const double p_a = lp(RRM, d);
+                const double up = st.rxp[(size_t)d * N + e] + p_a;
+                const double noise = up - p_a;
+                if (!(noise >= 0.0)) fl |= GW_FLAG_REFEXC;
+                granted = receive(m, ber_bpsk_dev(p_a, noise, c.ten_log_br), an, br, hdr_bits, (double)(La * 8) * c.coded_factor, fl);
+                st.rxp[(size_t)d * N + e] = up + (-p_a);
+            } else {
+                s_d_old = st.rxs[(int64_t)d * N + e];
+                s_d = s_h1[d * S + s_d_old];
+                granted = decode(m, s_cls[d * S + s_d], cls_valid, s_ber[d * S + s_d], an, br, hdr_bits,
+                                 (double)(La * 8) * c.coded_factor, fl);
+            }
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
@@ -147,19 +163,30 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const uint32_t inv20_d = c.inv20[d];
             int n_data = 0;
             uint32_t n_ticks = 0;                                         // counter ticks inside this step
-            const uint8_t s_r_old = st.rxs[(int64_t)RRM * N + e];
+            const uint8_t s_r_old = DYN ? (uint8_t)0 : st.rxs[(int64_t)RRM * N + e];
             uint8_t s_r = s_r_old;
-            const uint8_t s_r1 = s_rr[d * S + s_r_old];                    // the RRM after one packet of d
-            const double ber_x1 = s_ber[(D + d) * S + s_r1];
-            const uint32_t cls_x1 = s_cls[(D + d) * S + s_r1];
+            const uint8_t s_r1 = DYN ? (uint8_t)0 : s_rr[d * S + s_r_old];        // the RRM after one packet of d
+            const double ber_x1 = DYN ? 0.0 : s_ber[(D + d) * S + s_r1];
+            const uint32_t cls_x1 = DYN ? 0u : s_cls[(D + d) * S + s_r1];
+            // live PHY: the RRM's (and a receive-mode peer's) received power, and the BER cached per noise value
+            double rx_r = 0.0, rx_r0 = 0.0, p_x = 0.0, ber_xd = 0.0, nz_r_prev = -1.0;
+            double rx_p = 0.0, rx_p0 = 0.0, p_p = 0.0, ber_pd = 0.0, nz_p_prev = -1.0;
+            if (DYN) { rx_r = rx_r0 = st.rxp[(size_t)RRM * N + e]; p_x = lp(d, RRM); }
             // receive-mode MAC at the destination (simple_stack.py:443-448): it is idle during d's window (its own
             // window, the only thing that blocks its phyIn handler, ended a slot before the previous step did)
             const int j_peer = (c.peer_receive && c.dest[d] != d) ? c.dest[d] : -1;
             uint8_t s_p = 0, s_p_old = 0;
             uint32_t n_peer = 0;
             if (j_peer >= 0) {
-                s_p_old = st.rxs[(int64_t)j_peer * N + e];
-                s_p = st.trans[((int64_t)j_peer * R + RRM) * S + s_p_old];    // it heard the announcement too
+                if (DYN) {
+                    rx_p0 = st.rxp[(size_t)j_peer * N + e];
+                    const double pa = lp(RRM, j_peer);
+                    rx_p = (rx_p0 + pa) + (-pa);                              // it heard the announcement too
+                    p_p = lp(d, j_peer);
+                } else {
+                    s_p_old = st.rxs[(int64_t)j_peer * N + e];
+                    s_p = st.trans[((int64_t)j_peer * R + RRM) * S + s_p_old];    // it heard the announcement too
+                }
             }
 
             // all counter ticks with wake < t (or <= t): counted in f64 four at a time (the running sum w += dt is the
@@ -209,7 +236,15 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     n_data++;
                     double ber_x = ber_x1;
                     uint32_t cls_x = cls_x1;
-                    if (idem) {
+                    if (DYN) {
+                        const double up = rx_r + p_x;
+                        const double noise = up - p_x;
+                        if (!(noise >= 0.0)) fl |= GW_FLAG_REFEXC;
+                        if (noise != nz_r_prev) { ber_xd = ber_bpsk_dev(p_x, noise, c.ten_log_br); nz_r_prev = noise; }
+                        ber_x = ber_xd;
+                        cls_x = GW_CLS_COMPUTE;
+                        rx_r = up + (-p_x);
+                    } else if (idem) {
                         s_r = s_r1;
                     } else {                                              // not seen with f64 link powers; full tables in HBM
                         s_r = st.trans[((int64_t)RRM * R + d) * S + s_r];
@@ -223,8 +258,18 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                         if (pv == c.counter_bound) dn = 1;
                     }
                     if (j_peer >= 0) {
-                        s_p = st.trans[((int64_t)j_peer * R + d) * S + s_p];
-                        const double ber_p = st.ber[((int64_t)j_peer * R + d) * S + s_p];
+                        double ber_p;
+                        if (DYN) {
+                            const double up = rx_p + p_p;
+                            const double noise = up - p_p;
+                            if (!(noise >= 0.0)) fl |= GW_FLAG_REFEXC;
+                            if (noise != nz_p_prev) { ber_pd = ber_bpsk_dev(p_p, noise, c.ten_log_br); nz_p_prev = noise; }
+                            ber_p = ber_pd;
+                            rx_p = up + (-p_p);
+                        } else {
+                            s_p = st.trans[((int64_t)j_peer * R + d) * S + s_p];
+                            ber_p = st.ber[((int64_t)j_peer * R + d) * S + s_p];
+                        }
                         if (receive(m, ber_p, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl)) n_peer++;
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
@@ -266,23 +311,47 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             ctr_new = (ctr0 >= bound) ? ctr0 : (ctr_new < bound ? ctr_new : bound);
 
             // ---- rx-power state of every radio (simple_stack.py:130-157) ---------------------
-            if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
-            if (s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
-            if (j_peer >= 0) {
-                if (s_p != s_p_old) st.rxs[(int64_t)j_peer * N + e] = s_p;
-                if (n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
-            }
-            for (int j = 0; j < D; ++j) {
-                if (j == d || j == j_peer) continue;
-                const uint8_t s0 = st.rxs[(int64_t)j * N + e];
-                uint8_t s;
-                if (idem) {
-                    s = n_data ? g_h2[(j * D + d) * S + s0] : s_h1[j * S + s0];
-                } else {
-                    s = st.trans[((int64_t)j * R + RRM) * S + s0];
-                    for (int n = 0; n < n_data; ++n) s = st.trans[((int64_t)j * R + d) * S + s];
+            if (DYN) {
+                if (rx_r != rx_r0) st.rxp[(size_t)RRM * N + e] = rx_r;
+                if (j_peer >= 0) {
+                    if (rx_p != rx_p0) st.rxp[(size_t)j_peer * N + e] = rx_p;
+                    if (n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
                 }
-                if (s != s0) st.rxs[(int64_t)j * N + e] = s;
+                for (int j = 0; j < D; ++j) {
+                    if (j == d || j == j_peer) continue;
+                    const double a0 = st.rxp[(size_t)j * N + e];
+                    const double pa = lp(RRM, j);
+                    double a = (a0 + pa) + (-pa);
+                    if (n_data) {
+                        const double pd = lp(d, j);
+                        for (int n = 0; n < n_data; ++n) {
+                            const double b = (a + pd) + (-pd);
+                            if (b == a) break;                            // a fixed point of the (+p, -p) pair stays one
+                            a = b;
+                        }
+                    }
+                    if (!(a >= 0.0)) fl |= GW_FLAG_REFEXC;
+                    if (a != a0) st.rxp[(size_t)j * N + e] = a;
+                }
+            } else {
+                if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
+                if (s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
+                if (j_peer >= 0) {
+                    if (s_p != s_p_old) st.rxs[(int64_t)j_peer * N + e] = s_p;
+                    if (n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
+                }
+                for (int j = 0; j < D; ++j) {
+                    if (j == d || j == j_peer) continue;
+                    const uint8_t s0 = st.rxs[(int64_t)j * N + e];
+                    uint8_t s;
+                    if (idem) {
+                        s = n_data ? g_h2[(j * D + d) * S + s0] : s_h1[j * S + s0];
+                    } else {
+                        s = st.trans[((int64_t)j * R + RRM) * S + s0];
+                        for (int n = 0; n < n_data; ++n) s = st.trans[((int64_t)j * R + d) * S + s];
+                    }
+                    if (s != s0) st.rxs[(int64_t)j * N + e] = s;
+                }
             }
 
             // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -------
@@ -414,12 +483,19 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
 #define GW_LAUNCH_GENERIC(DT_)                                                                                   \
     do {                                                                                                        \
         if (st.pe_stats)                                                                                        \
-            hipLaunchKernelGGL((ct_step_kernel<DT_, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,      \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, true, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, \
                                st, device, duration, obs, reward, done);                                        \
         else                                                                                                    \
-            hipLaunchKernelGGL((ct_step_kernel<DT_, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,     \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, false, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, \
                                st, device, duration, obs, reward, done);                                        \
     } while (0)
+    if (st.rxp) {                                        // live PHY (open noise-state set / per-env geometry): runtime-D instantiation
+        if (st.pe_stats)
+            hipLaunchKernelGGL((ct_step_kernel<0, true, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, device, duration, obs, reward, done);
+        else
+            hipLaunchKernelGGL((ct_step_kernel<0, false, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, device, duration, obs, reward, done);
+        return check_launch();
+    }
     switch (st.D) {
     case 2:  GW_LAUNCH_GENERIC(2); break;
     case 3:  GW_LAUNCH_GENERIC(3); break;

@@ -8,6 +8,7 @@
 //     (devices/core.py:52-86 -> PositionalAttenuationModel, physical.py:380-386 -> FsplAttenuation,
 //     attenuation_models.py:28-36): link powers per env, rebuilt on the device by gw_set_position(s).
 // MAC queues keep the exact suffix encoding of the default kernel (gw_queue.h): queues do not depend on the PHY.
+// (With GW_CFG_EXPLICIT_QUEUE the same live PHY runs inside the generic kernel: ct_step.hip, instantiation DYN.)
 // Same walk as ct_step_sfx.hip; what differs is A.2/A.4: every transmission i -> j adds its
 // power to the listeners' received power, the receiver's BER is physical.py:25-58,208-212 on the device libm
 // (log10 / pow / sqrt: last-ulp differences from CPython's libm -- they only enter error sums that are rounded to
@@ -28,28 +29,6 @@ template <class T>
 __device__ __forceinline__ void st_(void* base, uint32_t byte_off, const T& v)
 {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
-}
-
-// physical.py:25-58 (Eb/N0, Q approximation), :82-98 (dBm helpers), :208-212 (BPSK) with the device libm
-__device__ __forceinline__ double ber_bpsk_dev(double sig_mw, double noise_mw, double ten_log_br)
-{
-    const double s = 10 * log10(sig_mw);
-    const double n = 10 * log10(noise_mw);
-    if (s <= n) return 0.5;
-    const double ratio_db = s - n - ten_log_br;
-    const double ratio = pow(10.0, ratio_db / 10);
-    const double x = sqrt(2 * ratio);
-    const double e = 2.718281828459045;
-    const double sqrt2pi = 2.5066282746310002;
-    return (1 - pow(e, -1.4 * x)) * pow(e, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
-}
-
-// link power from -> to (mW) of env e: per-env table [from][to][N] or the handle's shared [from][to]
-template <bool PER_ENV>
-__device__ __forceinline__ double link(const GwState& st, int R, int from, int to, uint32_t e)
-{
-    if (PER_ENV) return st.prx_env[((size_t)(from * R + to)) * (size_t)st.N + e];
-    return st.prx_tab[from * R + to];
 }
 
 template <bool PER_ENV>
@@ -113,7 +92,7 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         const int Ld = ndigits(slots);
         const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(Ld * 8)));
         k.tx++;
-        const double p_a = link<PER_ENV>(st, R, RRM, d, e);               // simple_stack.py:111
+        const double p_a = gw_link<PER_ENV>(st, R, RRM, d, e);               // simple_stack.py:111
         const double rx_d0 = st.rxp[(size_t)d * N + e];
         const double up_d = rx_d0 + p_a;                                  // :82  (+p) at the start of the transmission
         const double noise_d = up_d - p_a;                                // :166-167 noise = received - signal
@@ -146,7 +125,7 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
             len_d = gw_len_after_ticks(len_d, kk, mult_d, kd);
         };
 
-        const double p_x = link<PER_ENV>(st, R, d, RRM, e);               // the RRM hears sender d
+        const double p_x = gw_link<PER_ENV>(st, R, d, RRM, e);               // the RRM hears sender d
         double rx_r = st.rxp[(size_t)RRM * N + e];
         const double rx_r0 = rx_r;
         double ber_x = 0.0, noise_prev = -1.0;
@@ -218,10 +197,10 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
             const uint32_t l0 = st.qb[oq + (uint32_t)j];
             st.qb[oq + (uint32_t)j] = (uint8_t)gw_len_after_ticks(l0, n_ticks, (uint32_t)c.mult[j], k);
             const double a0 = st.rxp[(size_t)j * N + e];
-            const double pa = link<PER_ENV>(st, R, RRM, j, e);
+            const double pa = gw_link<PER_ENV>(st, R, RRM, j, e);
             double a = (a0 + pa) + (-pa);
             if (n_data) {
-                const double pd = link<PER_ENV>(st, R, d, j, e);
+                const double pd = gw_link<PER_ENV>(st, R, d, j, e);
                 for (int n = 0; n < n_data; ++n) {
                     const double b = (a + pd) + (-pd);
                     if (b == a) break;                                    // a fixed point of the (+p, -p) pair stays one

@@ -124,8 +124,6 @@ int validate(const gw_config& c)
     }
     if ((c.flags & (GW_CFG_NO_COUNTER_TRAFFIC | GW_CFG_PEER_RECEIVE | GW_CFG_FLOAT_DURATION)) && !(c.flags & GW_CFG_EXPLICIT_QUEUE))
         return fail(GW_EUNSUPPORTED, "GW_CFG_NO_COUNTER_TRAFFIC / PEER_RECEIVE / FLOAT_DURATION need GW_CFG_EXPLICIT_QUEUE");
-    if ((c.flags & GW_CFG_PER_ENV_GEOMETRY) && (c.flags & GW_CFG_EXPLICIT_QUEUE))
-        return fail(GW_EUNSUPPORTED, "GW_CFG_PER_ENV_GEOMETRY needs the default queue mode");
     for (int a = 0; a <= c.num_devices; ++a)
         for (int b = 0; b <= c.num_devices; ++b)
             if (!(c.extra_att_db[a][b] == c.extra_att_db[b][a]) || (a == b && c.extra_att_db[a][b] != 0.0))
@@ -179,7 +177,7 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
                 int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
-    if (env->dyn) return gw_launch_step_dyn(env->st, env->cst_host, device, duration, obs, reward, done, stream);
+    if (env->dyn && env->st.tk) return gw_launch_step_dyn(env->st, env->cst_host, device, duration, obs, reward, done, stream);
     return env->st.tk ? gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, stream)
                       : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
@@ -349,10 +347,6 @@ int gw_create(const gw_config* cfg, gw_env** out)
     const bool explicit_q = (cfg->flags & GW_CFG_EXPLICIT_QUEUE) != 0;
     const bool per_env_geo = (cfg->flags & GW_CFG_PER_ENV_GEOMETRY) != 0;
     env->dyn = (per_env_geo || env->tab.overflow) ? 1 : 0;
-    if (env->dyn && explicit_q) {
-        gw_destroy(env);
-        return fail(GW_EUNSUPPORTED, "%s: this geometry needs the live-PHY kernel, which runs in the default queue mode only", msg);
-    }
     uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr; uint8_t* d_blob = nullptr;
     if (explicit_q) {
         TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
@@ -1012,6 +1006,22 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         HIP_TRY(hipMemcpy(p.data(), st.peer_rx, p.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         uint32_t* o = (uint32_t*)dst;
         for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = p[(size_t)i * N + e];
+        return GW_OK;
+    }
+    if (!strcmp(field, "pos") || !strcmp(field, "link_power")) {
+        if (!st.prx_env) return fail(GW_EFIELD, "field %s needs GW_CFG_PER_ENV_GEOMETRY", field);
+        const int per = field[0] == 'p' ? R * 2 : R * R;
+        NEED(N * per, double); double* o = (double*)dst;
+        std::vector<double> v((size_t)N * per);
+        HIP_TRY(hipMemcpy(v.data(), field[0] == 'p' ? st.pos_env : st.prx_env, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t e = 0; e < N; ++e) for (int i = 0; i < per; ++i) o[e * per + i] = v[(size_t)i * N + e];
+        return GW_OK;
+    }
+    if (!strcmp(field, "rx_power") && st.rxp) {          // live-PHY mode: the f64 itself, [R][N] on the device
+        NEED(N * R, double); double* o = (double*)dst;
+        std::vector<double> rx((size_t)N * R);
+        HIP_TRY(hipMemcpy(rx.data(), st.rxp, rx.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = rx[(size_t)r * N + e];
         return GW_OK;
     }
     if (!strcmp(field, "rx_power")) {

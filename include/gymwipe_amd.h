@@ -126,7 +126,7 @@ typedef struct gw_config {
 #define GW_CFG_FLOAT_DURATION 16            /* the assignment duration is passed as a float (test_stack.py:197):
                                                the announcement payload is len(str(float(slots))) bytes */
 
-#define GW_CFG_PER_ENV_GEOMETRY 32          /* positions per ENVIRONMENT (default queue mode): every env starts with cfg.pos and
+#define GW_CFG_PER_ENV_GEOMETRY 32          /* positions per ENVIRONMENT (either queue mode): every env starts with cfg.pos and
                                                gw_set_position(s) moves radios between steps -- Position.set,
                                                devices/core.py:52-86; link powers per env, rebuilt on the device (ct_step_dyn.hip) */
 

@@ -80,7 +80,7 @@ def test_open_noise_state_layouts_are_accepted_not_refused(native_lib):
 def _mk(N, D, **kw):
     from gymwipe_amd import VecCounterTrafficEnv
     from oracle.ct_oracle import CtOracle, default_config
-    env = VecCounterTrafficEnv(N, num_devices=D, **kw)
+    env = VecCounterTrafficEnv(N, num_devices=D, **kw)                       # (explicit_queue / per_env_stats pass through)
     cfg = default_config(D, positions=kw.get("positions"), mult=kw.get("multiplicity"), rrm_pos=kw.get("rrm_position"))
     return env, CtOracle(N, D, config=cfg, nthreads=8)
 
@@ -239,9 +239,102 @@ def test_position_api_needs_the_per_env_mode():
     with pytest.raises(nat.NativeError) as ei:
         env.set_position(0, 1.0, 1.0)
     assert ei.value.code == nat.EUNSUPPORTED
-    with pytest.raises(nat.NativeError):
-        VecCounterTrafficEnv(64, num_devices=2, per_env_geometry=True, explicit_queue=True)
     env2 = VecCounterTrafficEnv(64, num_devices=2, per_env_geometry=True)
     with pytest.raises(nat.NativeError) as ei:
         env2.set_position(3, 1.0, 1.0)                          # radio index out of range (0, 1, 2 = the RRM)
     assert ei.value.code == nat.EINVAL
+
+
+# ---- the live PHY inside the generic kernel (GW_CFG_EXPLICIT_QUEUE): any traffic, receive-mode MACs ---------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", OPEN_LAYOUTS)
+def test_open_layout_on_the_generic_kernel(seed):
+    """The same layouts with explicit queues: the generic kernel's live-PHY instantiation.  Bit-exact incl. queue contents
+    and received powers (host link tables)."""
+    D, pos, rrm = open_state_set_layout(seed)
+    N, K = 256, 48
+    env, orc = _mk(N, D, positions=pos, rrm_position=rrm, explicit_queue=True, per_env_stats=True)
+    dev, dur = action_stream(seed + 1, K, N, D)
+    assert (env.reset().cpu().numpy() == orc.reset()).all()
+    for k in range(K):
+        if k == 25:
+            assert (env.reset().cpu().numpy() == orc.reset()).all()
+        _step_both(env, orc, dev, dur, k)
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="open layout, generic kernel")
+    env.check()
+
+
+@pytest.mark.gpu
+def test_receive_mode_macs_on_an_open_layout_against_layer1():
+    """Receive-mode MACs (peers hand up what they decode) + scripted extra packets on a layout without a finite noise-state
+    set: only the generic kernel's live PHY can run this; the reference-faithful event-driven model is the oracle."""
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv
+    from oracle.des_model import CounterTrafficModel
+    D, pos, rrm = open_state_set_layout(OPEN_LAYOUTS[0])
+    N, K = 3, 24
+    env = VecCounterTrafficEnv(N, D, explicit_queue=True, peer_receive=True, positions=pos, rrm_position=rrm)
+    models = [CounterTrafficModel(D, positions=pos, rrm_pos=rrm, peer_receive=True) for _ in range(N)]
+    rng = np.random.default_rng(4)
+    env.reset()
+    for m in models:
+        m.reset()
+    for k in range(K):
+        dev = rng.integers(0, D, N, dtype=np.int32)
+        dur = rng.integers(0, 20, N, dtype=np.int32)
+        if k % 5 == 2:                                             # an arbitrary packet into a queue (SimpleNetworkDevice.send)
+            s = int(rng.integers(0, D))
+            nb = rng.integers(1, 40, N, dtype=np.int32)
+            env.enqueue(s, torch.from_numpy(nb))
+            for e, m in enumerate(models):
+                m.enqueue(s, int(nb[e]))
+        o, r, d, _ = env.step({"device": torch.from_numpy(dev), "duration": torch.from_numpy(dur)})
+        for e, m in enumerate(models):
+            mo, mr, md, _ = m.step(int(dev[e]), int(dur[e]))
+            assert (int(o[e]), float(r[e])) == (mo, float(mr)), (k, e)
+    now, qlen = env.get_state("now"), env.get_state("qlen")
+    peer, rxp, q = env.get_state("peer_received"), env.get_state("rx_power"), env.get_state("queue")
+    for e, m in enumerate(models):
+        s = m.snapshot()
+        assert float(now[e]).hex() == s["now"].hex() and qlen[e].tolist() == s["qlen"], e
+        assert peer[e].tolist() == s["peer_received"], e
+        assert [float(v).hex() for v in rxp[e]] == [v.hex() for v in s["rx_power"]], e
+        for i in range(D):
+            assert q[e, i, :qlen[e, i]].tolist() == s["queues"][i], (e, i)
+    assert int(peer.sum()) > 0
+    env.check()
+
+
+@pytest.mark.gpu
+def test_per_env_geometry_with_the_generic_kernel():
+    """Per-env positions + moves between steps with explicit queues (one oracle handle per env)."""
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv
+    from oracle.ct_oracle import CtOracle, default_config
+    N, D, K = 24, 3, 36
+    rng = np.random.default_rng(21)
+    pos = np.zeros((N, D + 1, 2))
+    pos[:, :D] = rng.uniform(-2.5, 2.5, (N, D, 2))
+    pos[:, D] = rng.uniform(-0.2, 0.2, (N, 2))
+    env = VecCounterTrafficEnv(N, num_devices=D, per_env_geometry=True, explicit_queue=True, per_env_stats=True)
+    env.set_positions(pos)
+    orcs = [CtOracle(1, D, config=default_config(D, positions=[tuple(p) for p in pos[e, :D]], rrm_pos=tuple(pos[e, D]))) for e in range(N)]
+    dev, dur = action_stream(6, K, N, D)
+    env.reset()
+    for o in orcs:
+        o.reset()
+    for k in range(K):
+        if k == 15:
+            nx, ny = rng.uniform(-3, 3, N), rng.uniform(-3, 3, N)
+            env.set_position(1, nx, ny)
+            for e, o in enumerate(orcs):
+                o.set_position(1, nx[e], ny[e])
+        o_, r_, d_, _ = env.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+        want = [orcs[e].step(dev[k, e:e + 1], dur[k, e:e + 1]) for e in range(N)]
+        assert (o_.cpu().numpy() == np.array([w[0][0] for w in want])).all() and (r_.cpu().numpy() == np.array([w[1][0] for w in want])).all(), k
+    for f in INT_FIELDS + ("now", "wake"):
+        a = env.get_state(f)
+        b = np.concatenate([o.get(f) for o in orcs])
+        assert (a.view(np.uint8) == b.view(np.uint8)).all(), f
+    a, b = env.get_state("rx_power"), np.concatenate([o.get("rx_power") for o in orcs])
+    assert np.max(np.abs(a - b) / b) < 1e-5

@@ -53,7 +53,7 @@ def algorithmic_bytes(D, env_steps, appended, popped):
 def state_bytes(D):
     """Bytes the default kernel itself must load + store per env-step: the minimum of its encoding."""
     rb = 16 * ((2 * D + 1 + 15) // 16)
-    return (16 + 16 + 16 + rb + 32 + 8) + (16 + 4 + 8 + rb + 32 + 9)
+    return (16 + 16 + 16 + rb + 8) + (16 + 4 + 8 + rb + 9)       # (+ 4-byte counter atomics only where a packet was popped / delivered)
 
 
 def measured_traffic(D, N):

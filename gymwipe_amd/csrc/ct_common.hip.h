@@ -16,7 +16,9 @@ struct TxTimes { double t_s, t_h, t_e, stop; };
 // form that gw_create validated for this configuration (gw_fastmath.h) and the plain form otherwise.
 // FAST = every fast form was validated for this handle (the usual case): the flags are compile-time constants and the
 // plain forms' code and the wave-uniform branches around them disappear from the instruction stream.
-template <bool FAST>
+// NOLIM (with FAST) = the host guarantees that every env's clock stays below the fast forms' validity limits for the
+// whole launch (gw_api.cpp keeps an upper bound of the simulated time): no per-lane limit tests either.
+template <bool FAST, bool NOLIM = false>
 struct StepMathT {
     double slot, inv_slot, fmod_limit, dr, rcp_dr, max_ber;
     int fast_fmod, fast_div, fast_decide;
@@ -29,6 +31,7 @@ struct StepMathT {
     // t % slot                                                       simtools.py:53
     __device__ __forceinline__ double slot_rem(double t) const
     {
+        if (FAST && NOLIM) return gw_fast_fmod(t, slot, inv_slot);
         return ((FAST || fast_fmod) && t < fmod_limit) ? gw_fast_fmod(t, slot, inv_slot) : fmod(t, slot);
     }
     // bits / dataRate                                                 physical.py:244-247, messages.py:67-75
@@ -82,6 +85,18 @@ __device__ __forceinline__ bool decode(const M& m, uint32_t cls, bool cls_valid,
     if (cls_valid && cls != GW_CLS_COMPUTE) return cls == GW_CLS_OK;
     uint32_t dummy = 0;
     return receive(m, ber, x, br, hdr_bits, pay_bits, dummy);
+}
+
+// Per-env event counters of the default-mode kernels: fire-and-forget atomics, issued only by lanes that have something to
+// add (a step without data pops nothing, flags are rare).  No load, no dependent store: nothing of it is on a wave's
+// critical path, and a quiet step moves no counter bytes at all.
+__device__ __forceinline__ void publish_env_counters(uint32_t* sa, uint32_t N, uint32_t e, uint32_t pop, uint32_t deliv,
+                                                     uint32_t bad, uint32_t fl)
+{
+    if (pop)   __hip_atomic_fetch_add(sa + (size_t)GW_SA_POP * N + e, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (deliv) __hip_atomic_fetch_add(sa + (size_t)GW_SA_DELIV * N + e, deliv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bad)   __hip_atomic_fetch_add(sa + (size_t)GW_SA_BAD * N + e, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fl)    __hip_atomic_fetch_or(sa + (size_t)GW_SA_FLAGS * N + e, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- live-PHY helpers (ct_step_dyn.hip and the generic kernel's live-PHY instantiation) ----

@@ -209,15 +209,10 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
 
     // ---- state -> registers --------------------------------------------------------------------------
     const uint32_t RB = GEN ? (uint32_t)st.RB : 16u * NWC;
-    const uint32_t o16 = e << 4, o32 = e << 5, oq = e * RB;
+    const uint32_t o16 = e << 4, oq = e * RB;
     const uint4 ip = ld<uint4>(st.ip, o16);
     const double2 tw = ld<double2>(st.tw, o16);
     const uint4 tk = ld<uint4>(st.tk, o16);
-    uint4 sa0 = ld<uint4>(st.sa, o32), sa1 = ld<uint4>(st.sa, o32 + 16u);
-    // used only after the loop: take them out of the in-order vmcnt queue now, or their first use would wait
-    // for every store issued before it
-    asm volatile("" : "+v"(sa0.x), "+v"(sa0.y), "+v"(sa0.z), "+v"(sa0.w));
-    asm volatile("" : "+v"(sa1.x), "+v"(sa1.y), "+v"(sa1.z), "+v"(sa1.w));
     typename ArrSel<GEN, DM>::rw len, tb;
     typename ArrSel<GEN, DM + 1>::rw sta;
     if constexpr (GEN) {
@@ -264,7 +259,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     }
 
     Tally kt = {0, 0, 0, 0, 0};
-    uint32_t k_steps = 0, k_bad = 0, fl = 0;
+    uint32_t k_bad = 0, fl = 0;
 
     // ---- per-step variables of the lane's current step -------------------------------------------------
     // Laziness that keeps the loop body small (all exact):
@@ -370,7 +365,6 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             last_abs = abs_d;
             r = r > 10 ? 10 : (r < -10 ? -10 : r);
             now = t_end;
-            k_steps++;
             finish = false;
             data_mode = false;
             mult_d = 0;                              // no addressed sender between steps
@@ -526,10 +520,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     st_(st.tw, o16, make_double2(now, wake));
     st_(st.tk, o16, tau);
     st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
-    sa0.x += k_steps; sa0.y += kt.tx; sa0.z += kt.deliv; sa0.w += kt.app;
-    sa1.x += kt.pop;  sa1.y += kt.drop; sa1.z += k_bad;  sa1.w |= fl;
-    st_(st.sa, o32, sa0);
-    st_(st.sa, o32 + 16u, sa1);
+    publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl);
 }
 
 template <int DT>

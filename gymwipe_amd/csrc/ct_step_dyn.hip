@@ -44,20 +44,19 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
     if (e >= N) return;
     const int D = c.D, R = D + 1, RRM = D;
     const uint32_t RB = (uint32_t)st.RB;
-    const uint32_t o16 = e << 4, oq = e * RB, o32 = e << 5;
+    const uint32_t o16 = e << 4, oq = e * RB;
 
     const int d = device[e];
     const int du = duration[e];
     const uint4 ip = ld<uint4>(st.ip, o16);
     const double2 tw = ld<double2>(st.tw, o16);
     const uint4 tk = ld<uint4>(st.tk, o16);
-    uint4 sa0 = ld<uint4>(st.sa, o32), sa1 = ld<uint4>(st.sa, o32 + 16u);
 
     const StepMath m(c);
     uint32_t rvm = ip.z;
     int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
     uint32_t dn = ip.w >> 31;
-    uint32_t fl = 0, k_bad = 0, k_steps = 0;
+    uint32_t fl = 0, k_bad = 0;
     Tally k = {0, 0, 0, 0, 0};
     const int pv = c.payload_value;
 
@@ -70,7 +69,6 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         reward[e] = 0.0f;
         done[e] = (uint8_t)dn;
     } else {
-        k_steps = 1;
         const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
         const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
         const int mh = c.mac_hdr;
@@ -225,10 +223,7 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         st_(st.tk, o16, tau);
         st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
     }
-    sa0.x += k_steps; sa0.y += k.tx; sa0.z += k.deliv; sa0.w += k.app;
-    sa1.x += k.pop;   sa1.y += k.drop; sa1.z += k_bad; sa1.w |= fl;
-    st_(st.sa, o32, sa0);
-    st_(st.sa, o32 + 16u, sa1);
+    publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl);
 }
 
 // FsplAttenuation._update + dbmToMilliwatts with the device libm (devices/core.py:88-95, attenuation_models.py:28-36,

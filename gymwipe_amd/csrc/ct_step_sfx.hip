@@ -88,7 +88,9 @@ __device__ __forceinline__ uint32_t word_of(const uint4& w, int i)          // i
 // DT == 0: any device count, the record's bytes are read and written in memory.
 // FEEDBACK: write the CounterTraffic interpreter's (obs, reward, done); the fused pendulum step (below) replaces them by
 // the plant's.  now_out: the env's clock after the step (unchanged for a bad action), live_out: e < N.
-template <int DT, bool FEEDBACK, bool FAST>
+// MODE 0: every fast form behind its run-time flag; 1: all validated at gw_create (FAST); 2: FAST and no env can reach the
+// fast forms' validity limits during this launch (host-side bound on the simulated time).
+template <int DT, bool FEEDBACK, int MODE>
 __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevConst& c,
                                                  const int32_t* __restrict__ device,
                                                  const int32_t* __restrict__ duration,
@@ -98,6 +100,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                                                  double& now_out, bool& live_out)
 {
     constexpr bool PACKED = DT > 0;                      // the byte record is held in registers
+    constexpr bool FAST = MODE >= 1, NOLIM = MODE == 2;
     constexpr int NWC = DT > 0 ? (2 * DT + 1 + 15) / 16 : 1;   // 16-byte words of the record
     const uint32_t N = (uint32_t)st.N;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,7 +133,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     }
 
     Tally k = {0, 0, 0, 0, 0};
-    uint32_t k_bad = 0, k_steps = 0;
+    uint32_t k_bad = 0;
 
     // ---- per-env state loads (before anything is stored) ---------------------------------------
     // Unconditional, from a clamped env index (lanes past N read env 0 and store nothing): as plain SSA values the
@@ -141,7 +144,6 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     const uint32_t el = live ? e : 0u;
     const uint32_t o16 = e << 4, o16l = el << 4;
     const uint32_t oq = e * RB, oql = el * RB;
-    const uint32_t o32 = e << 5, o32l = el << 5;
     const int d = device[el];
     const int du = duration[el];
     const uint4 ip = ld<uint4>(st.ip, o16l);
@@ -150,13 +152,11 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     uint4 qw[NWC];
 #pragma unroll
     for (int w = 0; w < NWC; ++w) qw[w] = PACKED ? ld<uint4>(st.qb, oql + 16u * w) : make_uint4(0u, 0u, 0u, 0u);
-    uint4 sa0 = ld<uint4>(st.sa, o32l);
-    uint4 sa1 = ld<uint4>(st.sa, o32l + 16u);
     now_out = tw.x;
     live_out = live;
 
     // ---- constants -> registers, under the shadow of the loads above --------------------------------
-    StepMathT<FAST> m(c);
+    StepMathT<FAST, NOLIM> m(c);
     double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
     double coded_factor = c.coded_factor, cls_limit = c.cls_limit, inv_interval = c.inv_interval;
     int pv = c.payload_value, cbound = c.counter_bound, max_duration = c.max_duration, dfactor = c.duration_factor;
@@ -192,11 +192,6 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
 #ifdef GW_STAMPS
         asm volatile("" : "+v"(rvm));         // diagnostic build: touch ip so that the stamp below sits after the state loads have landed
 #endif
-        // The counter record is loaded with the rest of the state but only used at the very end.  vmcnt counts
-        // loads AND stores in order on this ISA, so a first use after the state stores would wait for those
-        // stores to be acknowledged (a full HBM write round trip on every wave's critical path): use it now.
-        PIN_V(sa0.x); PIN_V(sa0.y); PIN_V(sa0.z); PIN_V(sa0.w);
-        PIN_V(sa1.x); PIN_V(sa1.y); PIN_V(sa1.z); PIN_V(sa1.w);
         STAMP(3);
         int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
         uint32_t dn = ip.w >> 31;
@@ -213,7 +208,6 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 done[e] = (uint8_t)dn;
             }
         } else {
-            k_steps = 1;
             const uint32_t bound = (uint32_t)cbound;
             const uint32_t base_bytes = (uint32_t)base_b;
             const bool idem = FAST || idem_i != 0;
@@ -278,7 +272,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             uint32_t s_r = s_r_old;
             const uint32_t mult_d = mi.x;
             const uint32_t inv16_d = mi.y;
-            const bool cls_valid = t_a < cls_limit;
+            const bool cls_valid = NOLIM || t_a < cls_limit;
 
             STAMP(4);
             const int slots = du * dfactor;                               // counter_traffic.py:149
@@ -455,16 +449,13 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
         }
         STAMP(11);
-        // ---- per-env event counters: {steps, tx, delivered, appended} {popped, dropped, bad, flags} ----
-        sa0.x += k_steps; sa0.y += k.tx; sa0.z += k.deliv; sa0.w += k.app;
-        sa1.x += k.pop;   sa1.y += k.drop; sa1.z += k_bad; sa1.w |= fl;
-        st_(st.sa, o32, sa0);
-        st_(st.sa, o32 + 16u, sa1);
+        // ---- per-env event counters (popped, delivered, bad, flags: the rest is derived from the state) ----
+        publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl);
     }
     STAMP(12);
 }
 
-template <int DT, bool FAST>
+template <int DT, int MODE>
 __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
                                                          const int32_t* __restrict__ device,
                                                          const int32_t* __restrict__ duration,
@@ -474,7 +465,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 {
     double now_new;
     bool live;
-    ct_step_sfx_body<DT, true, FAST>(st, c, device, duration, obs, reward, done, now_new, live);
+    ct_step_sfx_body<DT, true, MODE>(st, c, device, duration, obs, reward, done, now_new, live);
 }
 
 // ---- BASELINE config 4: env.step() of the pendulum env in ONE launch ------------------------------------------------
@@ -485,7 +476,7 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 // components: the wave's 64 plant states go through an LDS transpose and four rounds of 16 envs each.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-template <bool FAST>
+template <int MODE>
 __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c, GwPlantDev p,
                                                        const int32_t* __restrict__ device,
                                                        const int32_t* __restrict__ duration,
@@ -509,7 +500,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
 
     double now_new;
     bool live;
-    ct_step_sfx_body<2, false, FAST>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
+    ct_step_sfx_body<2, false, MODE>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
 
     // substeps to take: n = round((now - last) / dt), nothing if time did not advance
     int n = 0;
@@ -586,8 +577,7 @@ __global__ void ct_init_sfx_kernel(GwState st)
     for (int b = 0; b < st.RB; ++b) st.qb[e * (uint32_t)st.RB + b] = 0;
     GwBp b0; b0.t0 = 0u; b0.c0 = 1u;
     st.bph[(size_t)e << 7] = b0;
-    st_(st.sa, e << 5, make_uint4(0u, 0u, 0u, 0u));
-    st_(st.sa, (e << 5) + 16u, make_uint4(0u, 0u, 0u, 0u));
+    for (int w = 0; w < GW_SA_WORDS; ++w) st.sa[(size_t)w * st.N + e] = 0u;
 }
 
 // counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound.
@@ -634,7 +624,7 @@ __global__ void ct_received_sfx_kernel(GwState st, int32_t* __restrict__ out)
 __global__ void ct_delivered_sfx_kernel(GwState st, uint32_t* __restrict__ out)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (uint32_t)st.N) out[e] = st.sa[(size_t)e * 8 + 2];
+    if (e < (uint32_t)st.N) out[e] = st.sa[(size_t)GW_SA_DELIV * st.N + e];
 }
 
 // the sticky per-env GW_FLAG_* bits (and, in the explicit-queue mode, their per-wave OR) back to zero
@@ -642,7 +632,7 @@ __global__ void ct_clear_flags_kernel(GwState st)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < st.N) {
-        if (st.sa) st.sa[(size_t)e * 8 + 7] = 0u;
+        if (st.sa) st.sa[(size_t)GW_SA_FLAGS * st.N + e] = 0u;
         if (st.flags) st.flags[e] = 0u;
     }
     if (st.totals && e < st.n_slots) st.totals[(size_t)e * GW_T_COUNT + GW_T_FLAGS] = 0ull;
@@ -650,17 +640,19 @@ __global__ void ct_clear_flags_kernel(GwState st)
 
 template <int DT>
 int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
-           int32_t* obs, float* reward, uint8_t* done, void* stream)
+           int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits)
 {
     const unsigned blk = (unsigned)st.block;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
-    // every exact fast form validated for this handle (gw_create): the instantiation without their fallbacks
-    if (cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks)
-        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, cst, device, duration, obs, reward, done);
+    // every exact fast form validated for this handle (gw_create): the instantiation without their fallbacks -- and, when
+    // the host can rule out that any env reaches their validity limits in this launch, without the per-lane limit tests
+    const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
+    if (fast && below_limits)
+        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
+    else if (fast)
+        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, 1>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
     else
-        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream,
-                           st, cst, device, duration, obs, reward, done);
+        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, 0>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
@@ -669,17 +661,17 @@ inline int ok_or_ehip() { return hipGetLastError() == hipSuccess ? GW_OK : GW_EH
 } // namespace
 
 int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
-                       int32_t* obs, float* reward, uint8_t* done, void* stream)
+                       int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits)
 {
     switch (st.D) {
-    case 2:  return launch<2>(st, cst, device, duration, obs, reward, done, stream);
-    case 3:  return launch<3>(st, cst, device, duration, obs, reward, done, stream);
-    case 4:  return launch<4>(st, cst, device, duration, obs, reward, done, stream);
-    case 6:  return launch<6>(st, cst, device, duration, obs, reward, done, stream);
-    case 8:  return launch<8>(st, cst, device, duration, obs, reward, done, stream);
-    case 16: return launch<16>(st, cst, device, duration, obs, reward, done, stream);
-    case 32: return launch<32>(st, cst, device, duration, obs, reward, done, stream);
-    default: return launch<0>(st, cst, device, duration, obs, reward, done, stream);
+    case 2:  return launch<2>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    case 3:  return launch<3>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    case 4:  return launch<4>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    case 6:  return launch<6>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    case 8:  return launch<8>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    case 16: return launch<16>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    case 32: return launch<32>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    default: return launch<0>(st, cst, device, duration, obs, reward, done, stream, below_limits);
     }
 }
 
@@ -712,13 +704,16 @@ int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream)
 }
 
 int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantDev& p, const int32_t* device, const int32_t* duration,
-                        int32_t* obs, float* reward, double* angle_deg, void* stream)
+                        int32_t* obs, float* reward, double* angle_deg, void* stream, bool below_limits)
 {
     const unsigned grid = (unsigned)((st.N + 63) / 64);
-    if (cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks)
-        hipLaunchKernelGGL(pend_step_kernel<true>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
+    const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
+    if (fast && below_limits)
+        hipLaunchKernelGGL(pend_step_kernel<2>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
+    else if (fast)
+        hipLaunchKernelGGL(pend_step_kernel<1>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
     else
-        hipLaunchKernelGGL(pend_step_kernel<false>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
+        hipLaunchKernelGGL(pend_step_kernel<0>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
     return ok_or_ehip();
 }
 

@@ -63,6 +63,10 @@ struct gw_env {
     int          nblocks;
     uint64_t     bytes;
     uint32_t*    pack_bad;    // device counter: elements gw_pack_feedback could not represent
+    double       t_bound;     // upper bound of every env's simulated time (start + steps launched x step_max)
+    double       step_max;    // upper bound of the simulated time one env.step() can take
+    double       t_limit;     // below this clock value every validated fast form and certainty class holds
+    uint64_t     n_steps;     // env.step() calls so far (gw_step + the steps of gw_rollout): per-env steps = n_steps - bad actions
     int          dyn;         // live-PHY mode (ct_step_dyn.hip): per-env geometry, or a geometry without a finite noise-state set
 };
 
@@ -178,7 +182,8 @@ int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
                 int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
     if (env->dyn && env->st.tk) return gw_launch_step_dyn(env->st, env->cst_host, device, duration, obs, reward, done, stream);
-    return env->st.tk ? gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, stream)
+    return env->st.tk ? gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, stream,
+                                           env->t_bound + env->step_max < env->t_limit)
                       : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
 
@@ -237,6 +242,43 @@ int gw_fill_dev_const(const gw_config& cfg, const GwHostTables& tab, GwDevConst&
 }
 
 int gw_validate_config(const gw_config& cfg) { return validate(cfg); }
+
+// Default mode: the per-env event counts.  Only {popped, delivered, bad actions, flags} are counted on the device
+// (GwState::sa); the rest follows from the state: every env.step() call steps every env unless its action was bad, every
+// step transmits one announcement and one data packet per pop, every counter tick appends mult_i packets at sender i, and
+// a packet that was appended is queued, popped or dropped.
+struct GwEnvCounts { std::vector<uint64_t> steps, tx, deliv, app, pop, drop, bad; std::vector<uint32_t> flags; };
+static int derive_env_counts(gw_env* env, GwEnvCounts& c)
+{
+    const GwState& st = env->st;
+    const int64_t N = st.N;
+    const int D = st.D, RB = st.RB;
+    std::vector<uint32_t> sa((size_t)N * GW_SA_WORDS), tk((size_t)N * 4);
+    std::vector<uint8_t> qb((size_t)N * RB);
+    HIP_TRY(hipMemcpy(sa.data(), st.sa, sa.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tk.data(), st.tk, tk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(qb.data(), st.qb, qb.size(), hipMemcpyDeviceToHost));
+    uint64_t mult_sum = 0;
+    for (int i = 0; i < D; ++i) mult_sum += (uint64_t)env->cfg.mult[i];
+    c.steps.resize(N); c.tx.resize(N); c.deliv.resize(N); c.app.resize(N); c.pop.resize(N); c.drop.resize(N); c.bad.resize(N);
+    c.flags.resize(N);
+    for (int64_t e = 0; e < N; ++e) {
+        uint64_t queued = 0;
+        for (int i = 0; i < D; ++i) queued += qb[(size_t)e * RB + i];
+        c.pop[e] = sa[(size_t)GW_SA_POP * N + e];
+        c.deliv[e] = sa[(size_t)GW_SA_DELIV * N + e];
+        c.bad[e] = sa[(size_t)GW_SA_BAD * N + e];
+        c.flags[e] = sa[(size_t)GW_SA_FLAGS * N + e];
+        c.steps[e] = env->n_steps - c.bad[e];
+        c.tx[e] = c.steps[e] + c.pop[e];
+        c.app[e] = (uint64_t)tk[(size_t)e * 4] * mult_sum;
+        c.drop[e] = c.app[e] - c.pop[e] - queued;
+    }
+    return GW_OK;
+}
+
+void gw_env_add_steps(gw_env* env, uint64_t n) { env->n_steps += n; env->t_bound += (double)n * env->step_max; }
+bool gw_env_below_limits(const gw_env* env) { return env->t_bound + env->step_max < env->t_limit; }
 
 // for the entry points that drive a gw_env together with another handle (gw_plant_api.cpp: gw_pendulum_step)
 int gw_env_internals(gw_env* env, const GwState** st, const GwDevConst** cst, int* hip_device)
@@ -334,6 +376,13 @@ int gw_create(const gw_config* cfg, gw_env** out)
     GwDevConst& k = env->cst_host;
     gw_fill_dev_const(*cfg, env->tab, k);
 
+    {
+        // one env.step() advances an env's clock by at most: slot alignment + announcement + window + guard slot
+        const double max_slots = (double)(cfg->max_duration - 1) * cfg->duration_factor;
+        env->step_max = ((max_slots + 3.0) * cfg->slot + (double)(cfg->mac_header_bytes + 16) * 8.0 / env->tab.data_rate) * (1.0 + 1e-9) + 1e-9;
+        env->t_bound = cfg->start_time;
+        env->t_limit = (k.fast_fmod && k.cls_limit > 0.0) ? (k.fmod_limit < k.cls_limit ? k.fmod_limit : k.cls_limit) : 0.0;
+    }
     GwState& st = env->st;
     st.N = N; st.D = D; st.R = R;
     {
@@ -357,7 +406,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
         st.RB = 16 * ((2 * D + 1 + 15) / 16);
         TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);     TRY_ALLOC(st.ip, N * 4);
         TRY_ALLOC(st.qb, N * st.RB);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
-        TRY_ALLOC(st.sa, N * 8);
+        TRY_ALLOC(st.sa, N * GW_SA_WORDS);
         {
             const char* rc_env = getenv("GW_ROLLOUT_CAP");      // steps per fused rollout launch
             int cap = rc_env ? atoi(rc_env) : 64;
@@ -477,6 +526,7 @@ int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
     if (rc) return rc;
     if (launch_step(env, device_dev, duration_dev, obs_dev, reward_dev, done_dev, stream))
         return fail(GW_EHIP, "step kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    gw_env_add_steps(env, 1);
     return GW_OK;
 }
 
@@ -503,11 +553,13 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
         }
         if (rc) return fail(GW_EHIP, "rollout kernel launch failed at step %d", s);
         s += chunk;
+        gw_env_add_steps(env, (uint64_t)chunk);
     }
     for (; s < steps; ++s) {                                   // generic path: one step launch per step
         const int64_t o = (int64_t)s * N;
         if (launch_step(env, device_dev + o, duration_dev + o, obs_dev + o, reward_dev + o, done_dev + o, stream))
             return fail(GW_EHIP, "step kernel launch failed at step %d", s);
+        gw_env_add_steps(env, 1);
     }
     return GW_OK;
 }
@@ -618,15 +670,13 @@ int gw_stats_read(gw_env* env, gw_stats* out)
     if (rc) return rc;
     unsigned long long t[GW_T_COUNT] = {0};
     HIP_TRY(hipDeviceSynchronize());
-    if (env->st.sa) {                                 // suffix mode: sum the per-env counter records
-        const int64_t N = env->st.N;
-        std::vector<uint32_t> sa((size_t)N * 8);
-        HIP_TRY(hipMemcpy(sa.data(), env->st.sa, sa.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (env->st.sa) {                                 // default mode: sum the per-env counts
+        GwEnvCounts c;
+        if ((rc = derive_env_counts(env, c))) return rc;
         memset(out, 0, sizeof *out);
-        for (int64_t e = 0; e < N; ++e) {
-            const uint32_t* r = &sa[(size_t)e * 8];
-            out->steps += r[0]; out->transmissions += r[1]; out->delivered += r[2]; out->appended += r[3];
-            out->popped += r[4]; out->dropped += r[5]; out->bad_actions += r[6]; out->flags_or |= r[7];
+        for (int64_t e = 0; e < env->st.N; ++e) {
+            out->steps += c.steps[e]; out->transmissions += c.tx[e]; out->delivered += c.deliv[e]; out->appended += c.app[e];
+            out->popped += c.pop[e]; out->dropped += c.drop[e]; out->bad_actions += c.bad[e]; out->flags_or |= c.flags[e];
         }
         return GW_OK;
     }
@@ -850,13 +900,14 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
     if (st.tk) {                                     // ---- suffix mode: packed records (ct_step_sfx.hip) ----
         {
             static const char* names[6] = {"n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped", "flags"};
-            static const int word[6] = {1, 2, 3, 4, 5, 7};
             for (int k = 0; k < 6; ++k)
                 if (!strcmp(field, names[k])) {
-                    std::vector<uint32_t> sa((size_t)N * 8);
-                    HIP_TRY(hipMemcpy(sa.data(), st.sa, sa.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                    if (k == 5) { NEED(N, uint32_t); uint32_t* o = (uint32_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = sa[(size_t)e * 8 + 7]; }
-                    else { NEED(N, uint64_t); uint64_t* o = (uint64_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = sa[(size_t)e * 8 + word[k]]; }
+                    GwEnvCounts c;
+                    if ((rc = derive_env_counts(env, c))) return rc;
+                    if (k == 5) { NEED(N, uint32_t); memcpy(dst, c.flags.data(), bytes); return GW_OK; }
+                    NEED(N, uint64_t);
+                    const std::vector<uint64_t>& v = k == 0 ? c.tx : (k == 1 ? c.deliv : (k == 2 ? c.app : (k == 3 ? c.pop : c.drop)));
+                    memcpy(dst, v.data(), bytes);
                     return GW_OK;
                 }
         }

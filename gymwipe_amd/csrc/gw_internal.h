@@ -61,8 +61,10 @@ struct GwState {
     uint16_t* ract;       // [N][rcap]  rollout scratch: packed actions (device | duration << 8)
     uint8_t*  rfb;        // [N][rcap]  rollout scratch: packed feedback bytes
     int32_t   rcap;       //            steps per fused rollout launch (multiple of 16)
-    uint32_t* sa;         // [N][8]     per-env event counters {steps, tx, delivered, appended, popped, dropped,
-                          //            bad actions, sticky flags}: plain load/add/store with the rest of the state
+    uint32_t* sa;         // [4][N]     per-env event counters that cannot be derived from the state: {popped, delivered, bad
+                          //            actions, sticky flags}, bumped by no-return atomics only where something happened.
+                          //            (steps = launches - bad; transmissions = steps + popped; appended = tau * sum(mult);
+                          //            dropped = appended - popped - sum(len): gw_api.cpp derives them)
     uint32_t* rvmask;     // [N]        bit i set <=> receivedValues[i] == payload_value
     int32_t*  last_abs;   // [N]        interpreter._lastAbsDifference
     uint8_t*  done;       // [N]        interpreter._done
@@ -106,6 +108,8 @@ struct GwBlobLayout {
 
 // decode certainty of a link in a given noise state (host: gw_tables.cpp; valid while t < fmod_limit)
 enum { GW_CLS_COMPUTE = 0, GW_CLS_OK = 1, GW_CLS_HDR_FAIL = 2, GW_CLS_PAY_FAIL = 3 };
+
+enum { GW_SA_POP = 0, GW_SA_DELIV = 1, GW_SA_BAD = 2, GW_SA_FLAGS = 3, GW_SA_WORDS = 4 };
 
 enum { GW_T_STEPS = 0, GW_T_TX, GW_T_DELIV, GW_T_APP, GW_T_POP, GW_T_DROP, GW_T_FLAGS, GW_T_BAD, GW_T_COUNT };
 
@@ -197,7 +201,7 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
 int gw_launch_received(const GwState& st, int32_t* out, void* stream);
 int gw_launch_enqueue(const GwState& st, int sender, const int32_t* payload_bytes, void* stream);
 int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
-                       int32_t* obs, float* reward, uint8_t* done, void* stream);
+                       int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits);
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
 int gw_launch_init_sfx(const GwState& st, void* stream);
 int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const int32_t* device, const int32_t* duration,

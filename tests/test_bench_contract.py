@@ -35,7 +35,7 @@ def test_bench_prints_one_contract_line():
         assert "error" not in d[sec], d[sec]
     assert d["repeats"] >= 1 and d["timed_step_indices_after_reset"][0] == 0 and d["us_per_step"]["min"] <= d["us_per_step"]["max"]
     assert r["frac"] <= 1.0 or "frac_above_one_because" in r
-    assert r["min_bytes_per_env_step"] == 189 and r["frac_min_bytes"] > 0
+    assert r["min_bytes_per_env_step"] == 125 and r["frac_min_bytes"] > 0
     assert c["by_devices"]["4"]["value"] == c["value"] and c["nproc"] >= c["cores"]
 
 

@@ -91,12 +91,16 @@ __device__ __forceinline__ bool decode(const M& m, uint32_t cls, bool cls_valid,
 // add (a step without data pops nothing, flags are rare).  No load, no dependent store: nothing of it is on a wave's
 // critical path, and a quiet step moves no counter bytes at all.
 __device__ __forceinline__ void publish_env_counters(uint32_t* sa, uint32_t N, uint32_t e, uint32_t pop, uint32_t deliv,
-                                                     uint32_t bad, uint32_t fl)
+                                                     uint32_t bad, uint32_t fl, uint32_t steps)
 {
-    if (pop)   __hip_atomic_fetch_add(sa + (size_t)GW_SA_POP * N + e, pop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (deliv) __hip_atomic_fetch_add(sa + (size_t)GW_SA_DELIV * N + e, deliv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (bad)   __hip_atomic_fetch_add(sa + (size_t)GW_SA_BAD * N + e, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (fl)    __hip_atomic_fetch_or(sa + (size_t)GW_SA_FLAGS * N + e, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pop)                                             // (delivered <= popped) one 64-bit atomic bumps both
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(sa) + e, (unsigned long long)pop | ((unsigned long long)deliv << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bad) __hip_atomic_fetch_add(sa + (size_t)2 * N + e, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fl)  __hip_atomic_fetch_or(sa + (size_t)3 * N + e, fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e == 0u)                                         // the handle's env.step() count: one lane per launch
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(sa + (size_t)4 * N), (unsigned long long)steps,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- live-PHY helpers (ct_step_dyn.hip and the generic kernel's live-PHY instantiation) ----

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     st_(st.tw, o16, make_double2(now, wake));
     st_(st.tk, o16, tau);
     st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
-    publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl);
+    publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl, (uint32_t)K);
 }
 
 template <int DT>

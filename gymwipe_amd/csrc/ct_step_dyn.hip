@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         st_(st.tk, o16, tau);
         st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
     }
-    publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl);
+    publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl, 1u);
 }
 
 // FsplAttenuation._update + dbmToMilliwatts with the device libm (devices/core.py:88-95, attenuation_models.py:28-36,

@@ -450,7 +450,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
         }
         STAMP(11);
         // ---- per-env event counters (popped, delivered, bad, flags: the rest is derived from the state) ----
-        publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl);
+        publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl, 1u);
     }
     STAMP(12);
 }
@@ -578,6 +578,7 @@ __global__ void ct_init_sfx_kernel(GwState st)
     GwBp b0; b0.t0 = 0u; b0.c0 = 1u;
     st.bph[(size_t)e << 7] = b0;
     for (int w = 0; w < GW_SA_WORDS; ++w) st.sa[(size_t)w * st.N + e] = 0u;
+    if (e == 0u) { st.sa[(size_t)4 * st.N] = 0u; st.sa[(size_t)4 * st.N + 1] = 0u; }
 }
 
 // counter_traffic.py:135-144 + :69-73 -- counters and interpreter only; time is NOT rewound.
@@ -624,7 +625,7 @@ __global__ void ct_received_sfx_kernel(GwState st, int32_t* __restrict__ out)
 __global__ void ct_delivered_sfx_kernel(GwState st, uint32_t* __restrict__ out)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < (uint32_t)st.N) out[e] = st.sa[(size_t)GW_SA_DELIV * st.N + e];
+    if (e < (uint32_t)st.N) out[e] = st.sa[(size_t)2 * e + 1];
 }
 
 // the sticky per-env GW_FLAG_* bits (and, in the explicit-queue mode, their per-wave OR) back to zero
@@ -632,7 +633,7 @@ __global__ void ct_clear_flags_kernel(GwState st)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < st.N) {
-        if (st.sa) st.sa[(size_t)GW_SA_FLAGS * st.N + e] = 0u;
+        if (st.sa) st.sa[(size_t)3 * st.N + e] = 0u;
         if (st.flags) st.flags[e] = 0u;
     }
     if (st.totals && e < st.n_slots) st.totals[(size_t)e * GW_T_COUNT + GW_T_FLAGS] = 0ull;

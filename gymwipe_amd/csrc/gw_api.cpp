@@ -66,7 +66,7 @@ struct gw_env {
     double       t_bound;     // upper bound of every env's simulated time (start + steps launched x step_max)
     double       step_max;    // upper bound of the simulated time one env.step() can take
     double       t_limit;     // below this clock value every validated fast form and certainty class holds
-    uint64_t     n_steps;     // env.step() calls so far (gw_step + the steps of gw_rollout): per-env steps = n_steps - bad actions
+    int          captured;    // a launch was recorded into a hipGraph: its replays advance the clocks unseen by t_bound
     int          dyn;         // live-PHY mode (ct_step_dyn.hip): per-env geometry, or a geometry without a finite noise-state set
 };
 
@@ -97,6 +97,10 @@ int select_device(const gw_env* env)
 
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
                 int32_t* obs, float* reward, uint8_t* done, void* stream);
+
+} // namespace
+bool gw_env_below_limits(gw_env* env, void* stream);
+namespace {
 
 int validate(const gw_config& c)
 {
@@ -183,7 +187,7 @@ int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
 {
     if (env->dyn && env->st.tk) return gw_launch_step_dyn(env->st, env->cst_host, device, duration, obs, reward, done, stream);
     return env->st.tk ? gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, stream,
-                                           env->t_bound + env->step_max < env->t_limit)
+                                           gw_env_below_limits(env, stream))
                       : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
 
@@ -253,23 +257,24 @@ static int derive_env_counts(gw_env* env, GwEnvCounts& c)
     const GwState& st = env->st;
     const int64_t N = st.N;
     const int D = st.D, RB = st.RB;
-    std::vector<uint32_t> sa((size_t)N * GW_SA_WORDS), tk((size_t)N * 4);
+    std::vector<uint32_t> sa((size_t)N * GW_SA_WORDS + 2), tk((size_t)N * 4);
     std::vector<uint8_t> qb((size_t)N * RB);
     HIP_TRY(hipMemcpy(sa.data(), st.sa, sa.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tk.data(), st.tk, tk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(qb.data(), st.qb, qb.size(), hipMemcpyDeviceToHost));
     uint64_t mult_sum = 0;
     for (int i = 0; i < D; ++i) mult_sum += (uint64_t)env->cfg.mult[i];
+    const uint64_t n_steps = (uint64_t)sa[(size_t)4 * N] | ((uint64_t)sa[(size_t)4 * N + 1] << 32);   // counted on the device
     c.steps.resize(N); c.tx.resize(N); c.deliv.resize(N); c.app.resize(N); c.pop.resize(N); c.drop.resize(N); c.bad.resize(N);
     c.flags.resize(N);
     for (int64_t e = 0; e < N; ++e) {
         uint64_t queued = 0;
         for (int i = 0; i < D; ++i) queued += qb[(size_t)e * RB + i];
-        c.pop[e] = sa[(size_t)GW_SA_POP * N + e];
-        c.deliv[e] = sa[(size_t)GW_SA_DELIV * N + e];
-        c.bad[e] = sa[(size_t)GW_SA_BAD * N + e];
-        c.flags[e] = sa[(size_t)GW_SA_FLAGS * N + e];
-        c.steps[e] = env->n_steps - c.bad[e];
+        c.pop[e] = sa[(size_t)2 * e];
+        c.deliv[e] = sa[(size_t)2 * e + 1];
+        c.bad[e] = sa[(size_t)2 * N + e];
+        c.flags[e] = sa[(size_t)3 * N + e];
+        c.steps[e] = n_steps - c.bad[e];
         c.tx[e] = c.steps[e] + c.pop[e];
         c.app[e] = (uint64_t)tk[(size_t)e * 4] * mult_sum;
         c.drop[e] = c.app[e] - c.pop[e] - queued;
@@ -277,8 +282,21 @@ static int derive_env_counts(gw_env* env, GwEnvCounts& c)
     return GW_OK;
 }
 
-void gw_env_add_steps(gw_env* env, uint64_t n) { env->n_steps += n; env->t_bound += (double)n * env->step_max; }
-bool gw_env_below_limits(const gw_env* env) { return env->t_bound + env->step_max < env->t_limit; }
+void gw_env_add_steps(gw_env* env, uint64_t n) { env->t_bound += (double)n * env->step_max; }
+// May this launch skip the per-lane validity-limit tests of the fast forms?  Only while the host's bound on the simulated
+// time is good: a launch recorded into a hipGraph can be replayed any number of times behind the host's back, so the first
+// capture seen on a handle switches the shortcut off for good (and the captured launch itself keeps the tests).
+bool gw_env_below_limits(gw_env* env, void* stream)
+{
+    if (env->captured) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        env->captured = 1;
+        return false;
+    }
+    (void)hipGetLastError();
+    return env->t_bound + env->step_max < env->t_limit;
+}
 
 // for the entry points that drive a gw_env together with another handle (gw_plant_api.cpp: gw_pendulum_step)
 int gw_env_internals(gw_env* env, const GwState** st, const GwDevConst** cst, int* hip_device)
@@ -406,7 +424,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
         st.RB = 16 * ((2 * D + 1 + 15) / 16);
         TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);     TRY_ALLOC(st.ip, N * 4);
         TRY_ALLOC(st.qb, N * st.RB);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
-        TRY_ALLOC(st.sa, N * GW_SA_WORDS);
+        TRY_ALLOC(st.sa, N * GW_SA_WORDS + 2);
         {
             const char* rc_env = getenv("GW_ROLLOUT_CAP");      // steps per fused rollout launch
             int cap = rc_env ? atoi(rc_env) : 64;

@@ -61,8 +61,9 @@ struct GwState {
     uint16_t* ract;       // [N][rcap]  rollout scratch: packed actions (device | duration << 8)
     uint8_t*  rfb;        // [N][rcap]  rollout scratch: packed feedback bytes
     int32_t   rcap;       //            steps per fused rollout launch (multiple of 16)
-    uint32_t* sa;         // [4][N]     per-env event counters that cannot be derived from the state: {popped, delivered, bad
-                          //            actions, sticky flags}, bumped by no-return atomics only where something happened.
+    uint32_t* sa;         // [4N + 2]   per-env event counters that cannot be derived from the state: {popped, delivered} bad
+                          //            actions, sticky flags (layout: GW_SA_WORDS), bumped by no-return atomics only where
+                          //            something happened; + the handle's step count.
                           //            (steps = launches - bad; transmissions = steps + popped; appended = tau * sum(mult);
                           //            dropped = appended - popped - sum(len): gw_api.cpp derives them)
     uint32_t* rvmask;     // [N]        bit i set <=> receivedValues[i] == payload_value
@@ -109,7 +110,10 @@ struct GwBlobLayout {
 // decode certainty of a link in a given noise state (host: gw_tables.cpp; valid while t < fmod_limit)
 enum { GW_CLS_COMPUTE = 0, GW_CLS_OK = 1, GW_CLS_HDR_FAIL = 2, GW_CLS_PAY_FAIL = 3 };
 
-enum { GW_SA_POP = 0, GW_SA_DELIV = 1, GW_SA_BAD = 2, GW_SA_FLAGS = 3, GW_SA_WORDS = 4 };
+// layout of GwState::sa (uint32 words): [0, 2N) = per env {popped, delivered} as ONE u64 (one atomic bumps both),
+// [2N, 3N) bad actions, [3N, 4N) sticky flags, then two words = the handle's env.step() count as a u64 (bumped by one lane
+// per launch, so that launches replayed from a hipGraph are counted too)
+enum { GW_SA_WORDS = 4 };
 
 enum { GW_T_STEPS = 0, GW_T_TX, GW_T_DELIV, GW_T_APP, GW_T_POP, GW_T_DROP, GW_T_FLAGS, GW_T_BAD, GW_T_COUNT };
 

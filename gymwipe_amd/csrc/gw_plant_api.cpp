@@ -21,7 +21,7 @@ int gw_env_internals(gw_env* env, const GwState** st, const GwDevConst** cst, in
 void gw_env_add_steps(gw_env* env, uint64_t n);                                                    // gw_api.cpp
 int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantDev& p, const int32_t* device, const int32_t* duration,
                         int32_t* obs, float* reward, double* angle_deg, void* stream, bool below_limits);  // ct_step_sfx.hip
-bool gw_env_below_limits(const gw_env* env);                                                      // gw_api.cpp
+bool gw_env_below_limits(gw_env* env, void* stream);                                                      // gw_api.cpp
 
 struct gw_plant {
     gw_plant_config cfg;
@@ -178,7 +178,7 @@ int gw_pendulum_step(gw_env* env, gw_plant* p, const int32_t* device_dev, const 
     if (st->D != 2) return gw_set_error(GW_EUNSUPPORTED, "gw_pendulum_step: the env's network has two assignable devices (sensor, controller)");
     if (st->N != p->dev.N || dev != p->cfg.hip_device) return gw_set_error(GW_EINVAL, "env and plant differ in num_envs or hip_device");
     PLANT_HIP(hipSetDevice(dev), (void)0);
-    if (gw_launch_pend_step(*st, *cst, p->dev, device_dev, duration_dev, obs_dev, reward_dev, angle_deg_dev, stream, gw_env_below_limits(env)))
+    if (gw_launch_pend_step(*st, *cst, p->dev, device_dev, duration_dev, obs_dev, reward_dev, angle_deg_dev, stream, gw_env_below_limits(env, stream)))
         return gw_set_error(GW_EHIP, "pendulum step launch failed");
     gw_env_add_steps(env, 1);
     return GW_OK;

@@ -550,7 +550,7 @@ def test_parity_with_silent_senders(explicit):
 
 
 @pytest.mark.parametrize("explicit", QUEUE_MODES)
-@pytest.mark.parametrize("t0", [1000.0, 123456.789, 1.05e6, 1.5e6, 3.0e6])
+@pytest.mark.parametrize("t0", [1000.0, 123456.789, 999999.6, 1.05e6, 1.5e6, 3.0e6])   # 999999.6: crosses the fast forms' 10^6 s limit mid-run
 def test_parity_at_large_simulated_times(t0, explicit):
     """Runs that START at a large simulated time (test hook `start_time`): coarser f64 binades for every time
     computation, and past the validity limits of the fast paths one after the other -- decode-certainty classes

@@ -392,11 +392,14 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 return s;
             };
             if (PACKED) {
+                const uint32_t heard_data = n_data ? 0xffffffffu : 0u;
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
                     Tally ki = {0, 0, 0, 0, 0};
                     const uint32_t li = gw_len_after_ticks(nb[i], n_ticks, mlt[i], ki);
-                    uint32_t si = n_data ? n2[i] : n1[i];
+                    // a bit-mask blend, not `n_data ? n2[i] : n1[i]`: with the flags compile-time constants the compiler turns the
+                    // latter into ONE select between the two ARRAYS, which sends both to scratch memory
+                    uint32_t si = (n2[i] & heard_data) | (n1[i] & ~heard_data);
                     if (!idem) si = heard_slow(i, nb[DT + i]);
                     if (i != d) { k.app += ki.app; k.drop += ki.drop; }   // d's own ticks were counted in the window
                     nb[i] = (i == d) ? len_d : li;

@@ -171,7 +171,9 @@ struct ConstMemArr {                                     // wave-uniform index i
 template <bool GEN, int N> struct ArrSel { typedef RegArr<N> rw; typedef ConstRegArr<N> ro; };
 template <int N> struct ArrSel<true, N> { typedef LdsArr rw; typedef ConstMemArr ro; };
 
-template <int DT>
+// MODE as in ct_step_sfx.hip: 0 run-time flags, 1 every fast form validated (FAST), 2 FAST and no env can reach the fast
+// forms' validity limits during this launch (host-side bound on the simulated time over all K steps).
+template <int DT, int MODE>
 __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevConst c, int K, int Kp,
                                                             const uint16_t* __restrict__ actions,
                                                             uint8_t* __restrict__ feedback)
@@ -240,10 +242,11 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
     uint32_t dn = ip.w >> 31;
 
-    const StepMath m(c);
+    constexpr bool FAST = MODE >= 1, NOLIM = MODE == 2;
+    const StepMathT<FAST, NOLIM> m(c);
     const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
     const double inv_interval = c.inv_interval, tie_filter = c.tie_filter;
-    const bool fast_ticks = c.fast_ticks != 0;
+    const bool fast_ticks = FAST || c.fast_ticks != 0;
     const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
     const int mh = c.mac_hdr, pv = c.payload_value;
     uint32_t live_mask = 0u;                             // any-D kernel: bit i = sender i is in a non-terminal noise state
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
             const int slots = du * c.duration_factor;
             pay_bytes = ndigits(slots);
             cur = now;
-            cls_valid = now < c.cls_limit;
+            cls_valid = NOLIM || now < c.cls_limit;
             const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];   // d after hearing the RRM
 #pragma unroll
             for (int i = 0; i < (GEN ? 0 : D); ++i) if (i == d) sta[i] = s_d;
@@ -524,11 +527,17 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
 }
 
 template <int DT>
-int launch_rollout(const GwState& st, const GwDevConst& cst, int K, int Kp, const uint16_t* act, uint8_t* fb, void* stream)
+int launch_rollout(const GwState& st, const GwDevConst& cst, int K, int Kp, const uint16_t* act, uint8_t* fb, void* stream, bool below_limits)
 {
     const unsigned blk = 64;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
-    hipLaunchKernelGGL((ct_rollout_sfx_kernel<DT>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
+    const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.fast_ticks;
+    if (fast && below_limits)
+        hipLaunchKernelGGL((ct_rollout_sfx_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
+    else if (fast)
+        hipLaunchKernelGGL((ct_rollout_sfx_kernel<DT, 1>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
+    else
+        hipLaunchKernelGGL((ct_rollout_sfx_kernel<DT, 0>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
@@ -536,7 +545,8 @@ int launch_rollout(const GwState& st, const GwDevConst& cst, int K, int Kp, cons
 
 // Returns GW_EUNSUPPORTED when this (D, K) has no fused kernel: the caller falls back to K step launches.
 int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const int32_t* device, const int32_t* duration,
-                          int32_t* obs, float* reward, uint8_t* done, uint16_t* act_buf, uint8_t* fb_buf, int k_cap, void* stream)
+                          int32_t* obs, float* reward, uint8_t* done, uint16_t* act_buf, uint8_t* fb_buf, int k_cap, void* stream,
+                          bool below_limits)
 {
     const int Kp = (K + 15) / 16 * 16;
     if (K <= 0 || Kp > k_cap || cst.max_duration > 0xfe) return GW_EUNSUPPORTED;
@@ -545,14 +555,14 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
     hipLaunchKernelGGL(pack_actions_kernel, dim3(g256), dim3(256), 0, (hipStream_t)stream, N, K, Kp, device, duration, act_buf);
     int rc;
     switch (st.D) {
-    case 2:  rc = launch_rollout<2>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    case 3:  rc = launch_rollout<3>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    case 4:  rc = launch_rollout<4>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    case 6:  rc = launch_rollout<6>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    case 8:  rc = launch_rollout<8>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    case 16: rc = launch_rollout<16>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    case 32: rc = launch_rollout<32>(st, cst, K, Kp, act_buf, fb_buf, stream); break;
-    default: rc = launch_rollout<0>(st, cst, K, Kp, act_buf, fb_buf, stream); break;   // any other D (5, 7, ..., 32): per-lane arrays in LDS
+    case 2:  rc = launch_rollout<2>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;
+    case 3:  rc = launch_rollout<3>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;
+    case 4:  rc = launch_rollout<4>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;
+    case 6:  rc = launch_rollout<6>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;
+    case 8:  rc = launch_rollout<8>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;
+    case 16: rc = launch_rollout<16>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;
+    case 32: rc = launch_rollout<32>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;
+    default: rc = launch_rollout<0>(st, cst, K, Kp, act_buf, fb_buf, stream, below_limits); break;   // any other D (5, 7, ..., 32): per-lane arrays in LDS
     }
     if (rc) return rc;
     hipLaunchKernelGGL(expand_feedback_kernel, dim3(g256), dim3(256), 0, (hipStream_t)stream, N, K, Kp, cst.counter_bound,

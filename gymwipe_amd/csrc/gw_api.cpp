@@ -564,7 +564,8 @@ int gw_rollout(gw_env* env, int32_t steps, const int32_t* device_dev, const int3
         const int32_t chunk = steps - s < env->st.rcap ? steps - s : env->st.rcap;
         const int64_t o = (int64_t)s * N;
         rc = gw_launch_rollout_sfx(env->st, env->cst_host, chunk, device_dev + o, duration_dev + o, obs_dev + o,
-                                   reward_dev + o, done_dev + o, env->st.ract, env->st.rfb, env->st.rcap, stream);
+                                   reward_dev + o, done_dev + o, env->st.ract, env->st.rfb, env->st.rcap, stream,
+                                   gw_env_below_limits(env, stream) && env->t_bound + (double)(chunk + 1) * env->step_max < env->t_limit);
         if (rc == GW_EUNSUPPORTED) {
             if (getenv("GW_ROLLOUT_STRICT")) return fail(GW_EUNSUPPORTED, "no fused rollout for this handle (GW_ROLLOUT_STRICT is set)");
             break;                                               // (steps > rollout capacity 0, max_duration > 254)

@@ -209,7 +209,8 @@ int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* 
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
 int gw_launch_init_sfx(const GwState& st, void* stream);
 int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const int32_t* device, const int32_t* duration,
-                          int32_t* obs, float* reward, uint8_t* done, uint16_t* act_buf, uint8_t* fb_buf, int k_cap, void* stream);
+                          int32_t* obs, float* reward, uint8_t* done, uint16_t* act_buf, uint8_t* fb_buf, int k_cap, void* stream,
+                          bool below_limits);
 int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream);
 int gw_launch_delivered_sfx(const GwState& st, uint32_t* out, void* stream);
 int gw_launch_clear_flags(const GwState& st, void* stream);          // ct_step_sfx.hip (both queue modes)

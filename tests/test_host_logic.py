@@ -218,3 +218,28 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu(native_lib):
     assert L.gw_get_state(None, b"now", None, 0) == nat.EINVAL
     assert L.gw_destroy(None) == nat.OK                                  # like free(NULL)
     assert L.gw_selftest_queue(1, 10, 0, 10) == nat.EINVAL
+
+
+def test_hot_kernels_use_no_scratch_memory(tmp_path):
+    """Every step / rollout kernel must keep its state in registers: private_segment_fixed_size == 0 for each
+    instantiation.  (Twice this build the compiler folded a select between array elements -- or between two arrays -- into
+    dynamic addressing of a stack copy, which costs 10-15 % of a launch and shows up nowhere else.)  Cross-compiles the
+    device code only; no GPU needed."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "gymwipe_amd", "csrc")
+    for src in ("ct_step_sfx.hip", "ct_rollout_sfx.hip", "ct_step.hip", "ct_step_dyn.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+                        "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", str(out), "-x", "hip",
+                        os.path.join(csrc, src)], check=True, capture_output=True, timeout=900)
+        text = out.read_text()
+        sizes = re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)
+        names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)
+        assert sizes and len(sizes) == len(names), src
+        bad = [(n, int(s)) for n, s in zip(names, sizes) if int(s) != 0]
+        assert not bad, "%s: kernels with scratch memory: %s" % (src, bad)

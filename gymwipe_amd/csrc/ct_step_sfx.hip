@@ -504,6 +504,9 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     double now_new;
     bool live;
     ct_step_sfx_body<2, false, MODE>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
+#ifdef GW_EXP_NO_EPILOGUE
+    if (now_new >= 0.0) return;
+#endif
 
     // substeps to take: n = round((now - last) / dt), nothing if time did not advance
     int n = 0;
@@ -525,6 +528,9 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     int nmax = n;                                        // wave-wide maximum of the substep counts
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
+#ifdef GW_EXP_NO_MFMA
+    nmax = 0;
+#endif
     while (nmax > 0) {                                   // one pass unless an env needs more than GW_PLANT_KMAX substeps
         const int cmax = nmax > GW_PLANT_KMAX ? GW_PLANT_KMAX : nmax;
         int chunk[4];

@@ -56,6 +56,8 @@ class VecInvertedPendulumEnv(BaseEnv):
         self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
         self._angle = torch.empty(n, dtype=torch.float64, device=self.device)
         self._done = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self._out_ptrs = (self._obs.data_ptr(), self._rew.data_ptr(), self._angle.data_ptr())   # fixed output buffers
+        self._fb = (self._obs, self._rew, self._done, {"Sensor angle": self._angle})
 
     def _feedback(self):
         torch = self._torch
@@ -82,16 +84,20 @@ class VecInvertedPendulumEnv(BaseEnv):
                     self.plant._h, self._now[0], self._now[1], self._obs.data_ptr(), self._rew.data_ptr(),
                     self._angle.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream))
             return self._obs, self._rew, self._done, {"Sensor angle": self._angle}
-        dev, dur = action["device"], action["duration"]
-        if not net._ready(dev):
-            dev = net._as_i32(dev, "device")
-        if not net._ready(dur):
-            dur = net._as_i32(dur, "duration")
-        with torch.cuda.device(self.device):
-            nat.check(net._L.gw_pendulum_step(net._h, self.plant._h, dev.data_ptr(), dur.data_ptr(), self._obs.data_ptr(),
-                                              self._rew.data_ptr(), self._angle.data_ptr(),
-                                              torch.cuda.current_stream(self.device).cuda_stream))
-        return self._obs, self._rew, self._done, {"Sensor angle": self._angle}
+        dev = net._checked(action["device"], "device")
+        dur = net._checked(action["duration"], "duration")
+        idx = net._dev_index
+        if torch._C._cuda_getDevice() == idx:                  # the one-process-per-GPU case: no context switch
+            rc = net._L.gw_pendulum_step(net._h, self.plant._h, dev.data_ptr(), dur.data_ptr(), self._out_ptrs[0],
+                                         self._out_ptrs[1], self._out_ptrs[2], torch._C._cuda_getCurrentRawStream(idx))
+        else:
+            with torch.cuda.device(self.device):
+                rc = net._L.gw_pendulum_step(net._h, self.plant._h, dev.data_ptr(), dur.data_ptr(), self._out_ptrs[0],
+                                             self._out_ptrs[1], self._out_ptrs[2],
+                                             torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            nat.check(rc)
+        return self._fb
 
     def render(self, mode="human", close=False):           # :115-116
         pass

@@ -45,6 +45,22 @@ for N in (64, 65536):
     lat.sort()
     out["N=%d" % N]["single_step_launch_to_sync_us_median"] = lat[len(lat) // 2] * 1e6
     out["N=%d" % N]["single_step_launch_to_sync_us_min"] = lat[0] * 1e6
+    # (c) the C side alone: gw_step through ctypes with every argument resolved beforehand
+    L, h = env._L, env._h
+    ptrs = [(acts[i]["device"].data_ptr(), acts[i]["duration"].data_ptr()) for i in range(64)]
+    o, r, d = env._obs.data_ptr(), env._rew.data_ptr(), env._done.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    best_c = 1e9
+    for rep in range(20):
+        env.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5, 25):
+            L.gw_step(h, ptrs[i][0], ptrs[i][1], o, r, d, stream)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        best_c = min(best_c, (t1 - t0) / 20)
+    out["N=%d" % N]["c_abi_enqueue_us_per_step"] = best_c * 1e6
     env.close()
 t0 = time.perf_counter()
 for _ in range(1000):

@@ -497,9 +497,11 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     const double u = p.u[el];
     const double tl = p.t_last[el];
     const unsigned long long nsub0 = p.nsub[el];
-    double p_op[GW_PLANT_KMAX / 4], q_op[GW_PLANT_KMAX / 4];       // MFMA A operands of every candidate group, by lane
+    double p_op[GW_PLANT_KMAX / 4];                       // MFMA A operand of every candidate group, by lane
 #pragma unroll
-    for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) { p_op[grp] = p.Pop[grp * 64 + lane]; q_op[grp] = p.Qop[grp * 64 + lane]; }
+    for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) p_op[grp] = p.Pop[grp * 64 + lane];
+    __shared__ double s_q[(GW_PLANT_KMAX + 1) * 4];      // Q_k[g]: the accumulated input vector of k substeps
+    for (int i = lane; i < (GW_PLANT_KMAX + 1) * 4; i += 64) s_q[i] = p.Qtab[i];
 
     double now_new;
     bool live;
@@ -515,14 +517,13 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     __syncthreads();
     const int g = lane >> 4, col = lane & 15;
     // four rounds of 16 envs, interleaved: the rounds' MFMA chains are independent, so they issue back to back
-    double xg[4], ug[4];
+    double xg[4], uq[4];
     int nq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int src = 16 * q + col;
         xg[q] = s_x[src][g];
-        const double uq = __shfl(u, src);
-        ug[q] = (g == 0) ? uq : 0.0;                     // B operand of the input MFMA: row 0 = u
+        uq[q] = __shfl(u, src);
         nq[q] = __shfl(n, src);
     }
     int nmax = n;                                        // wave-wide maximum of the substep counts
@@ -540,19 +541,25 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
 #pragma unroll
         for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
             if (cmax > 4 * grp) {                        // wave-uniform
-                const double a_p = p_op[grp], a_q = q_op[grp];
+                const double a_p = p_op[grp];
+                v4f64 acc[4];                            // the four rounds' products are independent: issued back to back
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg[q], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_q, ug[q], acc, 0, 0, 0);
+                    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg[q], zero, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
                     const int r = chunk[q] - (4 * grp + 1);           // which candidate is mine (if any)
-                    if (r >= 0 && r < 4) xn[q] = r == 0 ? acc.x : (r == 1 ? acc.y : (r == 2 ? acc.z : acc.w));
+                    if (r >= 0 && r < 4) xn[q] = r == 0 ? acc[q].x : (r == 1 ? acc[q].y : (r == 2 ? acc[q].z : acc[q].w));
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { xg[q] = xn[q]; nq[q] -= chunk[q]; }
+        for (int q = 0; q < 4; ++q) {                    // + Q_k u: rank one, one fused multiply-add per lane
+            xg[q] = chunk[q] > 0 ? fma(s_q[chunk[q] * 4 + g], uq[q], xn[q]) : xn[q];
+            nq[q] -= chunk[q];
+        }
         nmax -= cmax;
     }
 #pragma unroll

@@ -125,7 +125,7 @@ struct GwPlantDev {
     double* t_last;               // [N]
     unsigned long long* nsub;     // [N] substeps applied so far
     const double* Pop;            // [KMAX/4][64]  A operand of the state MFMA, by lane
-    const double* Qop;            // [KMAX/4][64]  A operand of the input MFMA, by lane
+    const double* Qtab;           // [KMAX+1][4]   Q_k = sum_{j<k} A^j B, the accumulated input vector of k substeps (Q_0 = 0)
     double dt, inv_dt;
 };
 

@@ -113,14 +113,14 @@ int gw_plant_create(const gw_plant_config* cfg, gw_plant** out)
             q[(size_t)(k + 1) * 4 + i] = s;
         }
     // MFMA A operands by lane: lane l = (row = l & 15, kk = l >> 4); row = 4*candidate + component
-    std::vector<double> pop((size_t)(K / 4) * 64), qop((size_t)(K / 4) * 64);
+    std::vector<double> pop((size_t)(K / 4) * 64), qop((size_t)(K + 1) * 4, 0.0);      // qop: Q_k[comp], row 0 = no substep
     for (int grp = 0; grp < K / 4; ++grp)
         for (int l = 0; l < 64; ++l) {
             const int row = l & 15, kk = l >> 4, cand = row >> 2, comp = row & 3, k = 4 * grp + 1 + cand;
             pop[(size_t)grp * 64 + l] = P[(size_t)k * 16 + comp * 4 + kk];
-            qop[(size_t)grp * 64 + l] = kk == 0 ? q[(size_t)k * 4 + comp] : 0.0;
         }
 
+    for (int k = 1; k <= K; ++k) for (int i = 0; i < 4; ++i) qop[(size_t)k * 4 + i] = q[(size_t)k * 4 + i];
     const int64_t N = cfg->num_envs;
     double *dP = nullptr, *dQ = nullptr;
     int rc;
@@ -128,7 +128,7 @@ int gw_plant_create(const gw_plant_config* cfg, gw_plant** out)
     PA(p->dev.x, N * 4); PA(p->dev.u, N); PA(p->dev.t_last, N); PA(p->dev.nsub, N);
     PA(dP, pop.size()); PA(dQ, qop.size());
 #undef PA
-    p->dev.N = N; p->dev.Pop = dP; p->dev.Qop = dQ; p->dev.dt = cfg->dt; p->dev.inv_dt = 1.0 / cfg->dt;
+    p->dev.N = N; p->dev.Pop = dP; p->dev.Qtab = dQ; p->dev.dt = cfg->dt; p->dev.inv_dt = 1.0 / cfg->dt;
     PLANT_HIP(hipMemcpy(dP, pop.data(), pop.size() * sizeof(double), hipMemcpyHostToDevice), gw_plant_destroy(p));
     PLANT_HIP(hipMemcpy(dQ, qop.data(), qop.size() * sizeof(double), hipMemcpyHostToDevice), gw_plant_destroy(p));
     if (gw_plant_launch_init(p->dev, cfg->x0, cfg->u0, nullptr)) { gw_plant_destroy(p); return gw_set_error(GW_EHIP, "plant init launch failed"); }

@@ -12,8 +12,9 @@
 // instruction holds component g of all four candidates in its four result registers
 // (row = g + 4*reg).  So the result of one application is already where the next application needs
 // it, and choosing the candidate that matches the env's substep count is a per-lane register select.
-// The input term is a second MFMA on the same accumulator: A-operand column 0 = sum_{j<k} A^j B,
-// B-operand row 0 = u.  Envs needing more than GW_PLANT_KMAX substeps go round the loop again.
+// The input term Q_k u (Q_k = sum_{j<k} A^j B) is rank one: ONE fused multiply-add per lane with the lane's own
+// Q_k[g] -- as a second MFMA per candidate group it used one K-row of four and doubled the matrix-core time.
+// Envs needing more than GW_PLANT_KMAX substeps go round the loop again.
 #include <hip/hip_runtime.h>
 #include "gw_internal.h"
 
@@ -43,20 +44,17 @@ __global__ __launch_bounds__(64) void plant_update_kernel(GwPlantDev p, const ch
         long long n = 0;
         if (live && now > tl) n = llrint((now - tl) * p.inv_dt);
         const long long n_total = n;
-        const double ug = (g == 0) ? u : 0.0;                       // B operand of the input MFMA: row 0 = u
         while (__any(n > 0)) {
             const int chunk = n > GW_PLANT_KMAX ? GW_PLANT_KMAX : (int)n;   // this round's substeps (0 = done)
             double xn = xg;
             for (int grp = 0; grp < GW_PLANT_KMAX / 4 && __any(chunk > 4 * grp); ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
                 const double a_p = p.Pop[grp * 64 + lane];
-                const double a_q = p.Qop[grp * 64 + lane];
                 v4f64 acc = {0.0, 0.0, 0.0, 0.0};
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_q, ug, acc, 0, 0, 0);
                 const int r = chunk - (4 * grp + 1);                 // which candidate is mine (if any)
                 if (r >= 0 && r < 4) xn = r == 0 ? acc.x : (r == 1 ? acc.y : (r == 2 ? acc.z : acc.w));
             }
-            xg = xn;
+            xg = chunk > 0 ? fma(p.Qtab[chunk * 4 + g], u, xn) : xn;        // + Q_k u
             n -= chunk;
         }
         if (live && n_total > 0) {

@@ -534,30 +534,38 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
 #endif
     while (nmax > 0) {                                   // one pass unless an env needs more than GW_PLANT_KMAX substeps
         const int cmax = nmax > GW_PLANT_KMAX ? GW_PLANT_KMAX : nmax;
-        int chunk[4];
-        double xn[4];
+        int chunk[4], mygrp[4];
+        v4f64 acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { chunk[q] = nq[q] > GW_PLANT_KMAX ? GW_PLANT_KMAX : nq[q]; xn[q] = xg[q]; }
+        for (int q = 0; q < 4; ++q) {
+            chunk[q] = nq[q] > GW_PLANT_KMAX ? GW_PLANT_KMAX : nq[q];
+            mygrp[q] = (chunk[q] - 1) >> 2;              // the candidate group holding this env's substep count (-1: none)
+            acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
+        }
+        // Every group's MFMA accumulates into the same registers, but an env's state enters only the MFMA of ITS group
+        // (B operand zero elsewhere: exact), so the accumulator ends up holding the four candidates of that one group and a
+        // single select per round remains.  (Selecting per group compiled to 3 nested exec-mask regions per group and
+        // round: 2.4 us of branching around 0.8 us of MFMA.)
 #pragma unroll
         for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
             if (cmax > 4 * grp) {                        // wave-uniform
-                const double a_p = p_op[grp];
-                v4f64 acc[4];                            // the four rounds' products are independent: issued back to back
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg[q], zero, 0, 0, 0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = chunk[q] - (4 * grp + 1);           // which candidate is mine (if any)
-                    if (r >= 0 && r < 4) xn[q] = r == 0 ? acc[q].x : (r == 1 ? acc[q].y : (r == 2 ? acc[q].z : acc[q].w));
+                    const double b = (mygrp[q] == grp) ? xg[q] : 0.0;
+#ifdef GW_EXP_FAKE_MFMA
+                    acc[q].x += p_op[grp] * b; acc[q].y += p_op[grp] + b; acc[q].z += b; acc[q].w -= b;
+#else
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(p_op[grp], b, acc[q], 0, 0, 0);
+#endif
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                    // + Q_k u: rank one, one fused multiply-add per lane
-            xg[q] = chunk[q] > 0 ? fma(s_q[chunk[q] * 4 + g], uq[q], xn[q]) : xn[q];
+        for (int q = 0; q < 4; ++q) {                    // my candidate, then + Q_k u: rank one, one fused multiply-add per lane
+            const int r = (chunk[q] - 1) & 3;
+            const double lo = (r & 1) ? acc[q].y : acc[q].x, hi = (r & 1) ? acc[q].w : acc[q].z;
+            const double pick = (r & 2) ? hi : lo;
+            xg[q] = chunk[q] > 0 ? fma(s_q[chunk[q] * 4 + g], uq[q], pick) : xg[q];
             nq[q] -= chunk[q];
         }
         nmax -= cmax;

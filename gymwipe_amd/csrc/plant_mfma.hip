@@ -46,15 +46,20 @@ __global__ __launch_bounds__(64) void plant_update_kernel(GwPlantDev p, const ch
         const long long n_total = n;
         while (__any(n > 0)) {
             const int chunk = n > GW_PLANT_KMAX ? GW_PLANT_KMAX : (int)n;   // this round's substeps (0 = done)
-            double xn = xg;
+            const int mygrp = (chunk - 1) >> 2;                             // the candidate group holding it (-1: none)
+            // every needed group's MFMA accumulates into the same registers; an env's state enters only the MFMA of its
+            // own group (B operand zero elsewhere: exact), so one select among four candidates remains (ct_step_sfx.hip,
+            // pend_step_kernel, performs the identical arithmetic for four tiles at once)
+            v4f64 acc = {0.0, 0.0, 0.0, 0.0};
             for (int grp = 0; grp < GW_PLANT_KMAX / 4 && __any(chunk > 4 * grp); ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
                 const double a_p = p.Pop[grp * 64 + lane];
-                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, xg, acc, 0, 0, 0);
-                const int r = chunk - (4 * grp + 1);                 // which candidate is mine (if any)
-                if (r >= 0 && r < 4) xn = r == 0 ? acc.x : (r == 1 ? acc.y : (r == 2 ? acc.z : acc.w));
+                const double b = (mygrp == grp) ? xg : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, b, acc, 0, 0, 0);
             }
-            xg = chunk > 0 ? fma(p.Qtab[chunk * 4 + g], u, xn) : xn;        // + Q_k u
+            const int r = (chunk - 1) & 3;
+            const double lo = (r & 1) ? acc.y : acc.x, hi = (r & 1) ? acc.w : acc.z;
+            const double pick = (r & 2) ? hi : lo;
+            xg = chunk > 0 ? fma(p.Qtab[chunk * 4 + g], u, pick) : xg;      // + Q_k u
             n -= chunk;
         }
         if (live && n_total > 0) {

@@ -497,9 +497,9 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     const double u = p.u[el];
     const double tl = p.t_last[el];
     const unsigned long long nsub0 = p.nsub[el];
-    double p_op[GW_PLANT_KMAX / 4];                       // MFMA A operand of every candidate group, by lane
+    __shared__ double s_pop[(GW_PLANT_KMAX / 4) * 64];    // MFMA A operand of every candidate group, by lane
 #pragma unroll
-    for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) p_op[grp] = p.Pop[grp * 64 + lane];
+    for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) s_pop[grp * 64 + lane] = p.Pop[grp * 64 + lane];
     __shared__ double s_q[(GW_PLANT_KMAX + 1) * 4];      // Q_k[g]: the accumulated input vector of k substeps
     for (int i = lane; i < (GW_PLANT_KMAX + 1) * 4; i += 64) s_q[i] = p.Qtab[i];
 
@@ -513,6 +513,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     // substeps to take: n = round((now - last) / dt), nothing if time did not advance
     int n = 0;
     if (mine && live && now_new > tl) n = (int)llrint((now_new - tl) * p.inv_dt);
+    STAMP(13);
     s_x[lane][0] = x01.x; s_x[lane][1] = x01.y; s_x[lane][2] = x23.x; s_x[lane][3] = x23.y;
     __syncthreads();
     const int g = lane >> 4, col = lane & 15;
@@ -529,9 +530,12 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     int nmax = n;                                        // wave-wide maximum of the substep counts
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
+    nmax = __builtin_amdgcn_readfirstlane(nmax);         // the same in every lane: a scalar, so that the group tests below are
+                                                         // real branches (as a vector value they became exec-mask regions around MFMAs)
 #ifdef GW_EXP_NO_MFMA
     nmax = 0;
 #endif
+    STAMP(14);
     while (nmax > 0) {                                   // one pass unless an env needs more than GW_PLANT_KMAX substeps
         const int cmax = nmax > GW_PLANT_KMAX ? GW_PLANT_KMAX : nmax;
         int chunk[4], mygrp[4];
@@ -546,18 +550,14 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
         // (B operand zero elsewhere: exact), so the accumulator ends up holding the four candidates of that one group and a
         // single select per round remains.  (Selecting per group compiled to 3 nested exec-mask regions per group and
         // round: 2.4 us of branching around 0.8 us of MFMA.)
+        const int ngrp = (cmax + 3) >> 2;                // scalar trip count; NOT unrolled: a per-group `if` made every
+#pragma unroll 1                                         // group a merge point that moved all accumulators AGPR -> VGPR -> AGPR
+        for (int grp = 0; grp < ngrp; ++grp) {           // candidates k0..k0+3, k0 = 4*grp + 1
+            const double a_p = s_pop[grp * 64 + lane];
 #pragma unroll
-        for (int grp = 0; grp < GW_PLANT_KMAX / 4; ++grp) {   // candidates k0..k0+3, k0 = 4*grp + 1
-            if (cmax > 4 * grp) {                        // wave-uniform
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double b = (mygrp[q] == grp) ? xg[q] : 0.0;
-#ifdef GW_EXP_FAKE_MFMA
-                    acc[q].x += p_op[grp] * b; acc[q].y += p_op[grp] + b; acc[q].z += b; acc[q].w -= b;
-#else
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(p_op[grp], b, acc[q], 0, 0, 0);
-#endif
-                }
+            for (int q = 0; q < 4; ++q) {
+                const double b = (mygrp[q] == grp) ? xg[q] : 0.0;
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, b, acc[q], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -570,6 +570,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
         }
         nmax -= cmax;
     }
+    STAMP(15);
 #pragma unroll
     for (int q = 0; q < 4; ++q) s_x[16 * q + col][g] = xg[q];
     __syncthreads();

@@ -234,7 +234,8 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
     csrc = os.path.join(ROOT, "gymwipe_amd", "csrc")
     for src in ("ct_step_sfx.hip", "ct_rollout_sfx.hip", "ct_step.hip", "ct_step_dyn.hip"):
         out = tmp_path / (src + ".s")
-        subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+                        "--offload-arch=gfx950",
                         "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", str(out), "-x", "hip",
                         os.path.join(csrc, src)], check=True, capture_output=True, timeout=900)
         text = out.read_text()

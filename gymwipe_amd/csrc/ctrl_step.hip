@@ -11,7 +11,8 @@
 //     as its angle (:39-41), the actuator takes value as the motor velocity (sliding_pendulum.py:154-155);
 //   * band assignment, announcement, window loop, slot alignment, BER integration, decode: exactly the step of
 //     ct_step.hip, whose helpers are shared.
-// One lane per environment; both MAC queues are explicit rings of payload values (packet sizes are constant).
+// One lane per environment; both MAC queues are explicit rings of payload values (packet sizes are constant); a step's
+// appends are staged in LDS and flushed once, the addressed queue's head is prefetched.
 // Event order at equal times follows the insertion rule: ticks before t first, then the delivery at t (its
 // completion event was queued when the transmission started, more than a tick interval ago), then a tick at t.
 #include "ct_common.hip.h"
@@ -25,7 +26,7 @@ constexpr int S = GW_MAX_NSTATES;
 
 struct Lane {                                               // everything indexed by a run-time device id goes through
     double now, wake, x[4], u, ang;                         // selects below: a dynamically indexed member array would
-    uint32_t ktick, head[2], len[2], got1, got2, ntx, ncmd, nsub, fl;   // send the whole struct to scratch memory
+    uint32_t ktick, got1, got2, ntx, ncmd, nsub, fl;        // send the whole struct to scratch memory
     uint32_t rxs[CR];
 };
 
@@ -34,25 +35,45 @@ __device__ __forceinline__ uint32_t pick(const uint32_t (&a)[CR], int i)
     return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
 }
 
-__device__ __forceinline__ void ring_push(double* ring, uint32_t& head, uint32_t& len, double v)
+// Queue handling of one step.  The values a step appends (the sensor's sample of every tick: up to 22; the controller's
+// command every `period` ticks) are staged in LDS, one column per lane, and written to the rings once, at the end of the
+// step; the first PRE entries at the addressed queue's head are loaded before the walk.  A pop therefore never waits for
+// memory inside the window loop (round 1: one dependent 8-byte load per transmission, one scattered 8-byte store per tick).
+//   queue = the last `len` values of its append stream; this step's appends are the last `app` of it:
+//   the head is a value of this step iff len <= app (then it is append number app - len).
+constexpr int NEW0 = 24, NEW1 = 24, PRE = 8;
+
+struct Q {                                                 // one queue during a step (scalars only: no dynamic indexing)
+    uint32_t head, len, app, head0, tail0;
+};
+
+__device__ __forceinline__ void q_push(Q& q, double* s_col, double v)      // deque(maxlen=100): drop the oldest when full
 {
-    if (len == GW_QUEUE_CAP) { head = (head + 1u) & GW_RING_MASK; len--; }   // deque(maxlen=100): drop the oldest
-    ring[(head + len) & GW_RING_MASK] = v;
-    len++;
+    if (q.len == GW_QUEUE_CAP) { q.head = (q.head + 1u) & GW_RING_MASK; q.len--; }
+    s_col[q.app << 6] = v;                                 // column of this lane: element j at [j * 64]
+    q.app++;
+    q.len++;
 }
 
 __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_t* __restrict__ device,
                                                        const int32_t* __restrict__ duration, int32_t* __restrict__ obs,
                                                        float* __restrict__ reward, double* __restrict__ angle_deg)
 {
+    __shared__ double s_new0[NEW0 * 64], s_new1[NEW1 * 64];
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.N) return;
+    double* col0 = s_new0 + (threadIdx.x & 63);
+    double* col1 = s_new1 + (threadIdx.x & 63);
     const GwDevConst& k = *c.cst;
     Lane L;
     L.now = c.now[e]; L.wake = c.wake[e]; L.u = c.u[e]; L.ang = c.ang[e]; L.ktick = c.ktick[e];
     for (int i = 0; i < 4; ++i) L.x[i] = c.x[e * 4 + i];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { const uint32_t hl = c.qhl[q * c.N + e]; L.head[q] = hl & 0xffu; L.len[q] = hl >> 8; }
+    Q q0, q1;
+    { const uint32_t hl = c.qhl[e]; q0.head = hl & 0xffu; q0.len = hl >> 8; }
+    { const uint32_t hl = c.qhl[c.N + e]; q1.head = hl & 0xffu; q1.len = hl >> 8; }
+    q0.app = q1.app = 0u;
+    q0.head0 = q0.head; q1.head0 = q1.head;
+    q0.tail0 = (q0.head + q0.len) & GW_RING_MASK; q1.tail0 = (q1.head + q1.len) & GW_RING_MASK;
 #pragma unroll
     for (int j = 0; j < CR; ++j) L.rxs[j] = c.rxs[j * c.N + e];
     L.got1 = c.got[e * 2]; L.got2 = c.got[e * 2 + 1];
@@ -68,10 +89,20 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
         const StepMath m(k);
         const double slot = k.slot, br = k.bit_rate, hd = k.hdr_dur, hdr_bits = k.hdr_bits, interval = k.counter_interval;
         const int mh = k.mac_hdr;
+        double* ringd = d == 0 ? ring0 : ring1;
+        // the first PRE values at the head of the addressed queue, issued now: they land during the announcement
+        double pre[PRE];
+        {
+            const uint32_t h0 = d == 0 ? q0.head : q1.head;
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) pre[i] = ringd[(h0 + (uint32_t)i) & GW_RING_MASK];
+        }
+        // the control tick test `(tick - start) % period == 0` as a running phase: one modulo per step, not per tick
+        uint32_t phase = L.ktick >= c.start ? (L.ktick - c.start) % c.period : 0u;
 
         // one counter tick: the sensor's process was created first, so it runs first at every tick time
-        auto tick_all = [&]() {
-            ring_push(ring0, L.head[0], L.len[0], L.x[2]);                     // sensor: sample, queue, ...
+        auto tick_all = [&]() __attribute__((always_inline)) {
+            q_push(q0, col0, L.x[2]);                                           // sensor: sample, queue, ...
             double nx[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                                      // ... then the plant advances one substep
@@ -85,14 +116,17 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
             for (int i = 0; i < 4; ++i) L.x[i] = nx[i];
             L.nsub++;
             const uint32_t kk = L.ktick;                                        // controller
-            if (kk >= c.start && (kk - c.start) % c.period == 0u && L.ang != 0.0) {
-                ring_push(ring1, L.head[1], L.len[1], -L.ang);
-                L.ncmd++;
+            if (kk >= c.start) {
+                if (phase == 0u && L.ang != 0.0) {
+                    q_push(q1, col1, -L.ang);
+                    L.ncmd++;
+                }
+                phase = phase + 1u == c.period ? 0u : phase + 1u;
             }
             L.ktick = kk + 1u;
             L.wake = L.wake + interval;                                         // running sum, as everywhere
         };
-        auto ticks_until = [&](double t, bool inclusive) {
+        auto ticks_until = [&](double t, bool inclusive) __attribute__((always_inline)) {
             while (inclusive ? (L.wake <= t) : (L.wake < t)) {
                 if (L.wake == t) L.fl |= GW_FLAG_TIE;
                 tick_all();
@@ -120,23 +154,35 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
             double cur = t_r;
             ticks_until(cur, false);                                            // the MAC's initialisation is URGENT: it goes first
             const int dst = d + 1;                                              // sensor -> controller, controller -> actuator
-            double* ring = d == 0 ? ring0 : ring1;
             const uint32_t sz = (uint32_t)(k.mac_hdr + k.net_hdr) + (d == 0 ? 2u : 1u);
-            uint32_t hd_q = d == 0 ? L.head[0] : L.head[1];                    // d's queue in scalars for the loop
+            const double need = m.over_rate((double)(sz * 8u));
+            const double pd = m.over_rate((double)(((int)sz - mh) * 8));
             for (;;) {
                 bool closed = false;
-                while ((d == 0 ? L.len[0] : L.len[1]) == 0u) {                  // wait for packet-added or the window timeout
+                while ((d == 0 ? q0.len : q1.len) == 0u) {                      // wait for packet-added or the window timeout
                     if (L.wake < stopw) { cur = L.wake; tick_all(); }
                     else { closed = true; break; }
                 }
                 if (closed) break;
-                const double need = m.over_rate((double)(sz * 8u));
                 if (!((stopw - cur) > need)) break;
-                hd_q = d == 0 ? L.head[0] : L.head[1];                          // (a tick may have dropped the oldest entry)
-                const double v = ring[hd_q];
-                hd_q = (hd_q + 1u) & GW_RING_MASK;
-                if (d == 0) { L.head[0] = hd_q; L.len[0]--; } else { L.head[1] = hd_q; L.len[1]--; }
-                const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(((int)sz - mh) * 8)));
+                // the head value (a tick may have dropped older entries meanwhile: head/len say where the head is now)
+                Q& qd = d == 0 ? q0 : q1;
+                double v;
+                if (qd.len <= qd.app) {                                         // appended in this step: from the LDS column
+                    v = (d == 0 ? col0 : col1)[(qd.app - qd.len) << 6];
+                } else {
+                    const uint32_t i = (qd.head - qd.head0) & GW_RING_MASK;     // how many older entries have gone already
+                    if (i < (uint32_t)PRE) {
+                        v = pre[0];
+#pragma unroll
+                        for (int j = 1; j < PRE; ++j) v = (i == (uint32_t)j) ? pre[j] : v;
+                    } else {
+                        v = ringd[qd.head];
+                    }
+                }
+                qd.head = (qd.head + 1u) & GW_RING_MASK;
+                qd.len--;
+                const TxTimes x = tx_times(m, cur, hd, pd);
                 L.ntx++;
                 all_hear(d);
                 const bool ok = receive(m, c.ber[((size_t)dst * CR + d) * S + pick(L.rxs, dst)], x, br, hdr_bits,
@@ -160,10 +206,14 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
     reward[e] = (float)fabs(180.0 - deg);
     if (angle_deg) angle_deg[e] = deg;
 
+    // this step's appends -> the rings: value j of queue q sits in slot (tail0 + j) & mask
+    for (uint32_t j = 0; j < q0.app; ++j) ring0[(q0.tail0 + j) & GW_RING_MASK] = col0[j << 6];
+    for (uint32_t j = 0; j < q1.app; ++j) ring1[(q1.tail0 + j) & GW_RING_MASK] = col1[j << 6];
+
     c.now[e] = L.now; c.wake[e] = L.wake; c.u[e] = L.u; c.ang[e] = L.ang; c.ktick[e] = L.ktick;
     for (int i = 0; i < 4; ++i) c.x[e * 4 + i] = L.x[i];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) c.qhl[q * c.N + e] = (uint16_t)(L.head[q] | (L.len[q] << 8));
+    c.qhl[e] = (uint16_t)(q0.head | (q0.len << 8));
+    c.qhl[c.N + e] = (uint16_t)(q1.head | (q1.len << 8));
 #pragma unroll
     for (int j = 0; j < CR; ++j) c.rxs[j * c.N + e] = (uint8_t)L.rxs[j];
     c.got[e * 2] = L.got1; c.got[e * 2 + 1] = L.got2;

@@ -87,6 +87,13 @@ int gw_ctrl_create(const gw_ctrl_config* cfg, gw_ctrl** out)
     if (cfg->ctrl_period_ticks < 1 || cfg->ctrl_start_tick < 0) return gw_set_error(GW_EINVAL, "ctrl_start_tick / ctrl_period_ticks out of range");
     int rc = gw_validate_config(cfg->net);
     if (rc) return rc;
+    {
+        // the step kernel stages a step's queue appends in LDS, 24 per queue: a step must not contain more counter ticks
+        const double step_max = ((double)(cfg->net.max_duration - 1) * cfg->net.duration_factor + 3.0) * cfg->net.slot
+                                + (double)(cfg->net.mac_header_bytes + 16) * 8.0 / (cfg->net.code_rate * cfg->net.bit_rate);
+        if (step_max / cfg->net.counter_interval + 2.0 > 24.0)
+            return gw_set_error(GW_EUNSUPPORTED, "more than 24 counter ticks can fall into one step with this duration range / counter interval");
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return gw_set_error(GW_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -97,6 +104,7 @@ int gw_ctrl_create(const gw_ctrl_config* cfg, gw_ctrl** out)
     c->cfg = *cfg;
     char msg[256] = "";
     rc = gw_build_tables(c->cfg.net, c->tab, msg, sizeof msg);
+    if (!rc && c->tab.overflow) rc = GW_EUNSUPPORTED;        // (the control-loop kernel keeps the byte noise states)
     if (rc) { delete c; return gw_set_error(rc, "%s", msg); }
     CTRL_HIP(hipSetDevice(cfg->net.hip_device), delete c);
     GwDevConst k;

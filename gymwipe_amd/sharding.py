@@ -161,7 +161,11 @@ class ChunkedFeedbackGather:
     def _submit(self, b, steps):
         self._pack(self.obs[b][:steps], self.reward[b][:steps], self.done[b][:steps], self.packed[b][:steps])
         self.filled[b] = steps
-        self.pending[b] = self._dist.all_gather_into_tensor(self.gathered[b].view(-1), self.packed[b].view(-1), async_op=True)
+        # only the rows that were filled travel: a partial chunk (the flush at the end of a short run) costs steps/chunk of a
+        # full one on the links, not all of it
+        cnt = steps * self.num_envs
+        out = self.gathered[b].view(-1)[:self.world * cnt]
+        self.pending[b] = self._dist.all_gather_into_tensor(out, self.packed[b].view(-1)[:cnt], async_op=True)
         return b
 
     def drain(self):
@@ -178,4 +182,5 @@ class ChunkedFeedbackGather:
 
     def result(self, b):
         """Packed feedback of the whole job for the chunk last gathered into buffer b: uint8[world][steps][N]."""
-        return self.gathered[b][:, :self.filled[b]]
+        steps = self.filled[b]
+        return self.gathered[b].view(-1)[:self.world * steps * self.num_envs].view(self.world, steps, self.num_envs)

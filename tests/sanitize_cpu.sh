@@ -20,6 +20,8 @@ from gymwipe_amd import _native as nat
 L = nat.lib()
 for mult in (1, 3, 7, 15):
     assert L.gw_selftest_queue(123 + mult, 20000, mult, 65536) == 0 and L.gw_selftest_queue(5, 20000, mult, 40) == 0
+for mult in (1, 3, 37, 100):                      # the generic kernel's run-length queues
+    assert L.gw_selftest_runq(77 + mult, 20000, mult, 65536) == 0 and L.gw_selftest_runq(9, 20000, mult, 9) == 0
 for D in (2, 4, 16, 32):
     cfg = nat.default_config(64, D); ns = C.c_int32()
     assert L.gw_selftest_fastmath(C.byref(cfg), C.byref(ns)) == 31

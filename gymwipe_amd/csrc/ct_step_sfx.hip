@@ -90,7 +90,9 @@ __device__ __forceinline__ uint32_t word_of(const uint4& w, int i)          // i
 // the plant's.  now_out: the env's clock after the step (unchanged for a bad action), live_out: e < N.
 // MODE 0: every fast form behind its run-time flag; 1: all validated at gw_create (FAST); 2: FAST and no env can reach the
 // fast forms' validity limits during this launch (host-side bound on the simulated time).
-template <int DT, bool FEEDBACK, int MODE>
+// HALF: 32 envs per 64-lane wave (lanes 0..31): twice the waves for a batch too small to give every SIMD one (the
+// pendulum step at 32 768 envs); the upper lanes idle through the walk and help in the plant's matrix-core rounds.
+template <int DT, bool FEEDBACK, int MODE, bool HALF = false>
 __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevConst& c,
                                                  const int32_t* __restrict__ device,
                                                  const int32_t* __restrict__ duration,
@@ -103,7 +105,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     constexpr bool FAST = MODE >= 1, NOLIM = MODE == 2;
     constexpr int NWC = DT > 0 ? (2 * DT + 1 + 15) / 16 : 1;   // 16-byte words of the record
     const uint32_t N = (uint32_t)st.N;
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = HALF ? blockIdx.x * 32u + (threadIdx.x & 31u) : blockIdx.x * blockDim.x + threadIdx.x;
     const int D = DT > 0 ? DT : c.D;
     const int R = D + 1, RRM = D;
     constexpr int S = GW_MAX_NSTATES;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     // 16-byte records stay in registers.  Loaded under `if (live)` into pre-initialised variables they became stack
     // objects, and for some device counts the compiler then folded the byte selects below into dynamic addressing
     // of such an object and moved it to LDS -- D = 3 and D = 6 ran three times slower than D = 4.
-    const bool live = e < N;
+    const bool live = e < N && (!HALF || threadIdx.x < 32u);
     const uint32_t el = live ? e : 0u;
     const uint32_t o16 = e << 4, o16l = el << 4;
     const uint32_t oq = e * RB, oql = el * RB;
@@ -479,18 +481,20 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 // components: the wave's 64 plant states go through an LDS transpose and four rounds of 16 envs each.
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
+template <int MODE, bool HALF>
 __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c, GwPlantDev p,
                                                        const int32_t* __restrict__ device,
                                                        const int32_t* __restrict__ duration,
                                                        int32_t* __restrict__ obs, float* __restrict__ reward,
                                                        double* __restrict__ angle_deg)
 {
-    __shared__ double s_x[64][5];                        // [env of the wave][component], padded: conflict-free both ways
+    constexpr int EPW = HALF ? 32 : 64;                  // envs per wave
+    constexpr int NR = EPW / 16;                         // matrix-core rounds of 16 envs each
+    __shared__ double s_x[EPW][5];                       // [env of the wave][component], padded: conflict-free both ways
     const int lane = threadIdx.x;
-    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
-    const bool mine = e < p.N;
-    const int64_t el = mine ? e : 0;
+    const int64_t e = (int64_t)blockIdx.x * EPW + (lane & (EPW - 1));
+    const bool mine = e < p.N && lane < EPW;
+    const int64_t el = e < p.N ? e : 0;
     // the plant's state, loaded before the step so that its latency hides behind the network walk
     const double2 x01 = *reinterpret_cast<const double2*>(p.x + el * 4);
     const double2 x23 = *reinterpret_cast<const double2*>(p.x + el * 4 + 2);
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
 
     double now_new;
     bool live;
-    ct_step_sfx_body<2, false, MODE>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
+    ct_step_sfx_body<2, false, MODE, HALF>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
 #ifdef GW_EXP_NO_EPILOGUE
     if (now_new >= 0.0) return;
 #endif
@@ -514,14 +518,14 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     int n = 0;
     if (mine && live && now_new > tl) n = (int)llrint((now_new - tl) * p.inv_dt);
     STAMP(13);
-    s_x[lane][0] = x01.x; s_x[lane][1] = x01.y; s_x[lane][2] = x23.x; s_x[lane][3] = x23.y;
+    if (lane < EPW) { s_x[lane][0] = x01.x; s_x[lane][1] = x01.y; s_x[lane][2] = x23.x; s_x[lane][3] = x23.y; }
     __syncthreads();
     const int g = lane >> 4, col = lane & 15;
-    // four rounds of 16 envs, interleaved: the rounds' MFMA chains are independent, so they issue back to back
-    double xg[4], uq[4];
-    int nq[4];
+    // NR rounds of 16 envs, interleaved: the rounds' MFMA chains are independent, so they issue back to back
+    double xg[NR], uq[NR];
+    int nq[NR];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NR; ++q) {
         const int src = 16 * q + col;
         xg[q] = s_x[src][g];
         uq[q] = __shfl(u, src);
@@ -530,18 +534,18 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     int nmax = n;                                        // wave-wide maximum of the substep counts
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
-    nmax = __builtin_amdgcn_readfirstlane(nmax);         // the same in every lane: a scalar, so that the group tests below are
-                                                         // real branches (as a vector value they became exec-mask regions around MFMAs)
+    nmax = __builtin_amdgcn_readfirstlane(nmax);         // the same in every lane: a scalar, so that the group loop below has a
+                                                         // scalar trip count (as a vector value it became exec masking around MFMAs)
+    STAMP(14);
 #ifdef GW_EXP_NO_MFMA
     nmax = 0;
 #endif
-    STAMP(14);
     while (nmax > 0) {                                   // one pass unless an env needs more than GW_PLANT_KMAX substeps
         const int cmax = nmax > GW_PLANT_KMAX ? GW_PLANT_KMAX : nmax;
-        int chunk[4], mygrp[4];
-        v4f64 acc[4];
+        int chunk[NR], mygrp[NR];
+        v4f64 acc[NR];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NR; ++q) {
             chunk[q] = nq[q] > GW_PLANT_KMAX ? GW_PLANT_KMAX : nq[q];
             mygrp[q] = (chunk[q] - 1) >> 2;              // the candidate group holding this env's substep count (-1: none)
             acc[q] = v4f64{0.0, 0.0, 0.0, 0.0};
@@ -555,13 +559,13 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
         for (int grp = 0; grp < ngrp; ++grp) {           // candidates k0..k0+3, k0 = 4*grp + 1
             const double a_p = s_pop[grp * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NR; ++q) {
                 const double b = (mygrp[q] == grp) ? xg[q] : 0.0;
                 acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_p, b, acc[q], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                    // my candidate, then + Q_k u: rank one, one fused multiply-add per lane
+        for (int q = 0; q < NR; ++q) {                   // my candidate, then + Q_k u: rank one, one fused multiply-add per lane
             const int r = (chunk[q] - 1) & 3;
             const double lo = (r & 1) ? acc[q].y : acc[q].x, hi = (r & 1) ? acc[q].w : acc[q].z;
             const double pick = (r & 2) ? hi : lo;
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     }
     STAMP(15);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s_x[16 * q + col][g] = xg[q];
+    for (int q = 0; q < NR; ++q) s_x[16 * q + col][g] = xg[q];
     __syncthreads();
     if (mine) {
         const double a0 = s_x[lane][0], a1 = s_x[lane][1], a2 = s_x[lane][2], a3 = s_x[lane][3];
@@ -732,14 +736,15 @@ int gw_launch_received_sfx(const GwState& st, int32_t* out, void* stream)
 int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantDev& p, const int32_t* device, const int32_t* duration,
                         int32_t* obs, float* reward, double* angle_deg, void* stream, bool below_limits)
 {
-    const unsigned grid = (unsigned)((st.N + 63) / 64);
+    // 32 envs per wave while that still leaves SIMDs without a wave (1024 SIMDs: up to 32 768 envs), else 64
+    const bool half = st.N <= 32 * 1024;
+    const unsigned grid = (unsigned)((st.N + (half ? 31 : 63)) / (half ? 32 : 64));
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
-    if (fast && below_limits)
-        hipLaunchKernelGGL(pend_step_kernel<2>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
-    else if (fast)
-        hipLaunchKernelGGL(pend_step_kernel<1>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
-    else
-        hipLaunchKernelGGL(pend_step_kernel<0>, dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg);
+    const int mode = fast ? (below_limits ? 2 : 1) : 0;
+#define GW_PEND(MODE_, HALF_) hipLaunchKernelGGL((pend_step_kernel<MODE_, HALF_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg)
+    if (half) { if (mode == 2) GW_PEND(2, true); else if (mode == 1) GW_PEND(1, true); else GW_PEND(0, true); }
+    else      { if (mode == 2) GW_PEND(2, false); else if (mode == 1) GW_PEND(1, false); else GW_PEND(0, false); }
+#undef GW_PEND
     return ok_or_ehip();
 }
 

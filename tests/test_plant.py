@@ -171,3 +171,24 @@ def test_pendulum_env_one_launch_at_config4_size():
     assert int(fused.network.get_state("flags").max()) & 3 == 0
     st = fused.network.stats()
     assert st["steps"] == N * K and st["transmissions"] > N * K          # announcements + the sensor's packets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [33000, 100])
+def test_pendulum_one_launch_both_wave_mappings(N):
+    """gw_pendulum_step maps 32 envs to a wave up to 32 768 envs (so that every SIMD gets one) and 64 beyond: both must equal
+    the two-launch form bit for bit (N = 100: ragged last wave of the 32-env mapping; 33 000: ragged last wave of the 64-env one)."""
+    import torch
+    from gymwipe_amd import VecInvertedPendulumEnv
+    from gymwipe_amd.actions import actions_torch
+    fused, split = VecInvertedPendulumEnv(N), VecInvertedPendulumEnv(N)
+    a_dev, a_dur = actions_torch(5, 0, N, 0, 24, 2, device="cuda")
+    for k in range(24):
+        act = {"device": a_dev[k], "duration": a_dur[k]}
+        o1, r1, d1, i1 = fused.step(act)
+        o2, r2, d2, i2 = split.step(act, fused=False)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(i1["Sensor angle"], i2["Sensor angle"]), k
+    assert (fused.plant.state().view(np.uint8) == split.plant.state().view(np.uint8)).all()
+    assert (fused.plant.get_state("substeps") == split.plant.get_state("substeps")).all()
+    for f in ("now", "wake", "qlen", "rx_power", "n_tx", "n_popped"):
+        assert (fused.network.get_state(f).view(np.uint8) == split.network.get_state(f).view(np.uint8)).all(), f

@@ -45,35 +45,10 @@ __device__ __forceinline__ T ld(const void* base, uint32_t byte_off)
 {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
-// State and output stores are write-through (sc1): a launch ends with the write-back of whatever its waves left dirty in the
-// L2s, and nothing of the next launch starts before that.  Waves finish at very different times (the slowest lane of a wave
-// gates it), so data written through as each wave ends is already on its way while the slow waves still run
-// (tools/launch_floor.hip: 7.22 -> 6.87 us per launch for 4 MB written; this kernel: -2 % per step).
 template <class T>
 __device__ __forceinline__ void st_(void* base, uint32_t byte_off, const T& v)
 {
-    char* p = reinterpret_cast<char*>(base) + byte_off;
-#ifdef GW_EXP_PLAIN_STORES
-    *reinterpret_cast<T*>(p) = v;
-#else
-    if constexpr (sizeof(T) == 16) {
-        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-        u32x4_ w; __builtin_memcpy(&w, &v, 16);
-        // (s_nop: a store of more than 8 bytes reads its data registers for two more cycles, and the compiler cannot see
-        // into the asm to keep the next write of them away, as it does for its own stores)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
-    } else if constexpr (sizeof(T) == 8) {
-        unsigned long long w; __builtin_memcpy(&w, &v, 8);
-        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
-    } else if constexpr (sizeof(T) == 4) {
-        unsigned w; __builtin_memcpy(&w, &v, 4);
-        asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
-    } else {
-        static_assert(sizeof(T) == 1, "st_: 1, 4, 8 or 16 bytes");
-        unsigned w = (unsigned)*reinterpret_cast<const uint8_t*>(&v);
-        asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
-    }
-#endif
+    gwk::gw_store_wt(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
 }
 
 // byte `idx` (0..15) of a 16-byte record held in four registers, idx not known at compile time.  The words are
@@ -606,15 +581,15 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c,
     if (mine) {
         const double a0 = s_x[lane][0], a1 = s_x[lane][1], a2 = s_x[lane][2], a3 = s_x[lane][3];
         if (n > 0) {
-            *reinterpret_cast<double2*>(p.x + e * 4) = make_double2(a0, a1);
-            *reinterpret_cast<double2*>(p.x + e * 4 + 2) = make_double2(a2, a3);
-            p.t_last[e] = now_new;
-            p.nsub[e] = nsub0 + (unsigned long long)n;
+            gwk::gw_store_wt(reinterpret_cast<double2*>(p.x + e * 4), make_double2(a0, a1));
+            gwk::gw_store_wt(reinterpret_cast<double2*>(p.x + e * 4 + 2), make_double2(a2, a3));
+            gwk::gw_store_wt(p.t_last + e, now_new);
+            gwk::gw_store_wt(p.nsub + e, nsub0 + (unsigned long long)n);
         }
         const double deg = a2 * (180.0 / 3.141592653589793);        // envs/inverted_pendulum.py:27-57
-        if (obs) obs[e] = (int32_t)deg;
-        if (reward) reward[e] = (float)fabs(180.0 - deg);
-        if (angle_deg) angle_deg[e] = deg;
+        if (obs) gwk::gw_store_wt(obs + e, (int32_t)deg);
+        if (reward) gwk::gw_store_wt(reward + e, (float)fabs(180.0 - deg));
+        if (angle_deg) gwk::gw_store_wt(angle_deg + e, deg);
     }
 }
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     constexpr bool FAST = MODE >= 1, NOLIM = MODE == 2;
     constexpr int NWC = DT > 0 ? (2 * DT + 1 + 15) / 16 : 1;   // 16-byte words of the record
     const uint32_t N = (uint32_t)st.N;
-    const uint32_t e = HALF ? blockIdx.x * 32u + (threadIdx.x & 31u) : blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = HALF ? blockIdx.x * 32u + (threadIdx.x & 31u) : blockIdx.x * 64u + threadIdx.x;   // 64-thread blocks
     const int D = DT > 0 ? DT : c.D;
     const int R = D + 1, RRM = D;
     constexpr int S = GW_MAX_NSTATES;
@@ -118,19 +118,23 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     constexpr int DM = DT > 0 ? DT : GW_MAX_DEVICES;
     constexpr GwBlobLayout LM(DM);
     const GwBlobLayout L(D);
-    __shared__ __attribute__((aligned(16))) uint8_t s_blob[LM.lds_total];
     const int n_ch = L.lds_total >> 4;                   // 16-byte chunks
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    constexpr int PER_FULL = ((LM.lds_total >> 4) + 63) / 64;            // chunks per thread in a 64-thread block
+    const int tid = threadIdx.x;
+    constexpr int nthr = 64;                                             // the launchers' block size
+    constexpr int PER_FULL = ((LM.lds_total >> 4) + 63) / 64;            // chunks per thread
     constexpr int PER = (DT > 0 && PER_FULL <= 8) ? PER_FULL : 1;
-    const bool one_pass = DT > 0 && PER_FULL <= 8 && nthr >= 64;
+    constexpr bool one_pass = DT > 0 && PER_FULL <= 8;
+    // (one pass: the LDS image is padded to whole rounds of 64 chunks and every lane loads and writes its chunk of every round
+    //  unconditionally -- lanes past the tables' end re-read chunk 0 into the padding -- so that the staging is straight-line
+    //  code: with a guard per chunk it was a chain of exec-mask regions, and the scalar loads of the remaining kernel
+    //  arguments ended up behind the first wait for the tables instead of in front of it)
+    __shared__ __attribute__((aligned(16))) uint8_t s_blob[one_pass ? PER * 64 * 16 : LM.lds_total];
     uint4 r_ch[PER];
     if (one_pass) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int ch = tid + i * nthr;
-            r_ch[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (ch < n_ch) r_ch[i] = ld<uint4>(st.blob, (uint32_t)ch << 4);
+            r_ch[i] = ld<uint4>(st.blob, (uint32_t)(ch < n_ch ? ch : 0) << 4);
         }
     }
 
@@ -146,8 +150,8 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     const uint32_t el = live ? e : 0u;
     const uint32_t o16 = e << 4, o16l = el << 4;
     const uint32_t oq = e * RB, oql = el * RB;
-    const int d = device[el];
-    const int du = duration[el];
+    int d = device[el];
+    int du = duration[el];
     const uint4 ip = ld<uint4>(st.ip, o16l);
     const double2 tw = ld<double2>(st.tw, o16l);
     const uint4 tk = ld<uint4>(st.tk, o16l);
@@ -156,8 +160,21 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     for (int w = 0; w < NWC; ++w) qw[w] = PACKED ? ld<uint4>(st.qb, oql + 16u * w) : make_uint4(0u, 0u, 0u, 0u);
     now_out = tw.x;
     live_out = live;
+    if (one_pass) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int ch = tid + i * nthr;
+            *reinterpret_cast<uint4*>(s_blob + ((uint32_t)ch << 4)) = r_ch[i];
+        }
+    } else {
+        for (int i = tid; i < n_ch; i += nthr) *reinterpret_cast<uint4*>(s_blob + ((uint32_t)i << 4)) = ld<uint4>(st.blob, (uint32_t)i << 4);
+    }
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
 
-    // ---- constants -> registers, under the shadow of the loads above --------------------------------
+    // ---- constants -> registers, after the tables are in LDS: the wave has waited for the table loads anyway, the arguments
+    //      arrived meanwhile, and no wait for them stands between the wave's start and its first vector loads --------------------------------
     StepMathT<FAST, NOLIM> m(c);
     double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
     double coded_factor = c.coded_factor, cls_limit = c.cls_limit, inv_interval = c.inv_interval;
@@ -170,18 +187,9 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i); PIN_S(fast_ticks);
     __builtin_amdgcn_sched_barrier(0);
 
-    if (one_pass) {
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int ch = tid + i * nthr;
-            if (ch < n_ch) *reinterpret_cast<uint4*>(s_blob + ((uint32_t)ch << 4)) = r_ch[i];
-        }
-    } else {
-        for (int i = tid; i < n_ch; i += nthr) *reinterpret_cast<uint4*>(s_blob + ((uint32_t)i << 4)) = ld<uint4>(st.blob, (uint32_t)i << 4);
-    }
-    STAMP(1);
-    __syncthreads();
-    STAMP(2);
+    // (the action is used unconditionally here, so that its loads stay at the top with the others: with every use inside
+    //  `if (live)` the compiler sank them into that block, behind the waits above)
+    PIN_V(d); PIN_V(du);
     const double* s_ber = reinterpret_cast<const double*>(s_blob + L.ber);
     const uint2* s_mi = reinterpret_cast<const uint2*>(s_blob + L.mi);
     const uint8_t* s_h1 = s_blob + L.h1;
@@ -460,14 +468,33 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     STAMP(12);
 }
 
-template <int DT, int MODE>
-__global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst c,
-                                                         const int32_t* __restrict__ device,
-                                                         const int32_t* __restrict__ duration,
-                                                         int32_t* __restrict__ obs,
-                                                         float* __restrict__ reward,
-                                                         uint8_t* __restrict__ done)
+// The leading arguments repeat what the step needs before anything else (the addresses of its first loads and the env
+// count that clamps them): as leading scalar arguments they are PRELOADED into SGPRs by the command processor
+// (-amdgpu-kernarg-preload-count, Makefile; 14 dwords at most), so the table and state loads issue in the wave's first
+// cycles.  Read from the GwState in the kernel-argument segment they cost two scalar-cache round trips (an s_load batch
+// for the table address and the block size, another for the state addresses) before the first vector load could leave.
+// The rest of the 1.2 KB of arguments is fetched under the shadow of those loads.  The tables sit gw_blob_header(D)
+// bytes before the `ip` records (gw_api.cpp), which saves their pointer.
+#define GW_LEAD_PARAMS uint32_t* __restrict__ ip, double* __restrict__ tw, uint32_t* __restrict__ tk, uint8_t* __restrict__ qb, \
+                       const int32_t* __restrict__ device, const int32_t* __restrict__ duration, uint32_t n_envs
+#define GW_LEAD_ARGS(st_) (st_).ip, (st_).tw, (st_).tk, (st_).qb, device, duration, (uint32_t)(st_).N
+template <int DT>
+__device__ __forceinline__ GwState with_lead(const GwState& st_arg, const GwDevConst& c, uint32_t* ip, double* tw, uint32_t* tk,
+                                             uint8_t* qb, uint32_t n_envs)
 {
+    GwState st = st_arg;
+    st.ip = ip; st.tw = tw; st.tk = tk; st.qb = qb; st.N = (int64_t)n_envs;
+    st.blob = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(DT > 0 ? DT : c.D);
+    return st;
+}
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(64) void ct_step_sfx_kernel(GW_LEAD_PARAMS, GwState st_arg, GwDevConst c,
+                                                        int32_t* __restrict__ obs,
+                                                        float* __restrict__ reward,
+                                                        uint8_t* __restrict__ done)
+{
+    const GwState st = with_lead<DT>(st_arg, c, ip, tw, tk, qb, n_envs);
     double now_new;
     bool live;
     ct_step_sfx_body<DT, true, MODE>(st, c, device, duration, obs, reward, done, now_new, live);
@@ -482,12 +509,11 @@ __global__ __launch_bounds__(256) void ct_step_sfx_kernel(GwState st, GwDevConst
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 template <int MODE, bool HALF>
-__global__ __launch_bounds__(64) void pend_step_kernel(GwState st, GwDevConst c, GwPlantDev p,
-                                                       const int32_t* __restrict__ device,
-                                                       const int32_t* __restrict__ duration,
+__global__ __launch_bounds__(64) void pend_step_kernel(GW_LEAD_PARAMS, GwState st_arg, GwDevConst c, GwPlantDev p,
                                                        int32_t* __restrict__ obs, float* __restrict__ reward,
                                                        double* __restrict__ angle_deg)
 {
+    const GwState st = with_lead<2>(st_arg, c, ip, tw, tk, qb, n_envs);
     constexpr int EPW = HALF ? 32 : 64;                  // envs per wave
     constexpr int NR = EPW / 16;                         // matrix-core rounds of 16 envs each
     __shared__ double s_x[EPW][5];                       // [env of the wave][component], padded: conflict-free both ways
@@ -672,17 +698,19 @@ template <int DT>
 int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
            int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits)
 {
-    const unsigned blk = (unsigned)st.block;
+    const unsigned blk = 64u;                          // the kernel's compile-time block size
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
     // every exact fast form validated for this handle (gw_create): the instantiation without their fallbacks -- and, when
     // the host can rule out that any env reaches their validity limits in this launch, without the per-lane limit tests
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
-    if (fast && below_limits)
-        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
-    else if (fast)
-        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, 1>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
-    else
-        hipLaunchKernelGGL((ct_step_sfx_kernel<DT, 0>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
+#define GW_STEP(MODE_) hipLaunchKernelGGL((ct_step_sfx_kernel<DT, MODE_>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, GW_LEAD_ARGS(st), \
+                                          st, cst, obs, reward, done)
+    switch (fast ? (below_limits ? 2 : 1) : 0) {
+    case 2:  GW_STEP(2); break;
+    case 1:  GW_STEP(1); break;
+    default: GW_STEP(0); break;
+    }
+#undef GW_STEP
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 
@@ -741,7 +769,7 @@ int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantD
     const unsigned grid = (unsigned)((st.N + (half ? 31 : 63)) / (half ? 32 : 64));
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
     const int mode = fast ? (below_limits ? 2 : 1) : 0;
-#define GW_PEND(MODE_, HALF_) hipLaunchKernelGGL((pend_step_kernel<MODE_, HALF_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, st, cst, p, device, duration, obs, reward, angle_deg)
+#define GW_PEND(MODE_, HALF_) hipLaunchKernelGGL((pend_step_kernel<MODE_, HALF_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, GW_LEAD_ARGS(st), st, cst, p, obs, reward, angle_deg)
     if (half) { if (mode == 2) GW_PEND(2, true); else if (mode == 1) GW_PEND(1, true); else GW_PEND(0, true); }
     else      { if (mode == 2) GW_PEND(2, false); else if (mode == 1) GW_PEND(1, false); else GW_PEND(0, false); }
 #undef GW_PEND

@@ -404,7 +404,9 @@ int gw_create(const gw_config* cfg, gw_env** out)
     GwState& st = env->st;
     st.N = N; st.D = D; st.R = R;
     {
-        const char* kb = getenv("GW_BLOCK");        // tuning knob: threads per workgroup of the step kernel
+        const char* kb = getenv("GW_BLOCK");        // tuning knob: threads per workgroup of the generic step kernel (the
+                                                    // suffix-queue kernels are fixed at 64: measured best, and a compile-time
+                                                    // block size keeps the hidden-argument load off their first cycles)
         st.block = kb ? atoi(kb) : 64;
         if (st.block != 16 && st.block != 32 && st.block != 64 && st.block != 128 && st.block != 256) st.block = 64;
     }
@@ -422,7 +424,13 @@ int gw_create(const gw_config* cfg, gw_env** out)
         TRY_ALLOC(st.rxs, N * R);
     } else {
         st.RB = 16 * ((2 * D + 1 + 15) / 16);
-        TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);     TRY_ALLOC(st.ip, N * 4);
+        TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);
+        {                                                   // the step tables and the `ip` records share a block: gw_blob_header()
+            uint8_t* blk = nullptr;
+            TRY_ALLOC(blk, (size_t)gw_blob_header(D) + (size_t)N * 16);
+            d_blob = blk;
+            st.ip = reinterpret_cast<uint32_t*>(blk + gw_blob_header(D));
+        }
         TRY_ALLOC(st.qb, N * st.RB);  TRY_ALLOC(st.bph, N * GW_RING_PHYS);
         TRY_ALLOC(st.sa, N * GW_SA_WORDS + 2);
         {
@@ -449,7 +457,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
 #endif
     TRY_ALLOC(d_cst, 1);       TRY_ALLOC(d_trans, tcount + 16);  TRY_ALLOC(d_ber, tcount);  TRY_ALLOC(d_cls, tcount);
     TRY_ALLOC(d_ber2, 2 * D * GW_MAX_NSTATES + 2);  TRY_ALLOC(d_cls2, 2 * D * GW_MAX_NSTATES + 16);
-    TRY_ALLOC(d_blob, GwBlobLayout(D).total + 16);
+    if (!d_blob) TRY_ALLOC(d_blob, GwBlobLayout(D).total + 16);
 #undef TRY_ALLOC
     st.cst = d_cst; st.trans = d_trans; st.ber = d_ber; st.cls = d_cls; st.ber2 = d_ber2; st.cls2 = d_cls2; st.blob = d_blob;
 

@@ -107,6 +107,14 @@ struct GwBlobLayout {
           total(h2 + D * D * GW_MAX_NSTATES) {}
 };
 
+// In the default (suffix-queue) mode the blob lives in the SAME allocation as the `ip` records, gw_blob_header(D) bytes
+// before them: the step kernel gets `ip` as a preloaded leading argument and derives the tables' address from it
+// (one pointer fewer among the 14 argument dwords the command processor can hand to a wave in SGPRs).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr int gw_blob_header(int D) { return (GwBlobLayout(D).total + 16 + 255) / 256 * 256; }
+
 // decode certainty of a link in a given noise state (host: gw_tables.cpp; valid while t < fmod_limit)
 enum { GW_CLS_COMPUTE = 0, GW_CLS_OK = 1, GW_CLS_HDR_FAIL = 2, GW_CLS_PAY_FAIL = 3 };
 

@@ -575,12 +575,12 @@ def test_parity_at_large_simulated_times(t0, explicit):
 
 @pytest.mark.parametrize("block", ["16", "32", "128", "256"])
 def test_parity_with_other_workgroup_sizes(block, monkeypatch):
-    """GW_BLOCK (read at gw_create) changes the launch shape of the step kernel and, below 64 threads, the way the
-    tables are staged in LDS; results must not change."""
+    """GW_BLOCK (read at gw_create) changes the launch shape of the generic step kernel and, below 64 threads, the way its
+    tables are staged in LDS; results must not change.  (The suffix-queue kernels have a compile-time block of 64.)"""
     monkeypatch.setenv("GW_BLOCK", block)
     N, K = 1000, 40                                    # not a multiple of any block size
     for D in (4, 5):                                   # templated and generic device counts
-        env, orc = _mk(N, D)
+        env, orc = _mk(N, D, explicit=True)
         dev, dur = action_stream(81, K, N, D)
         _run(env, orc, dev, dur, reset_every=16)
 

@@ -157,8 +157,13 @@ class VecCounterTrafficEnv(BaseEnv):
         self.config = cfg
 
         self._h = C.c_void_p()
+        self._hv = 0
+        self._fast = nat.fast()
+        self._cuda_get_device = torch._C._cuda_getDevice
+        self._cuda_raw_stream = torch._C._cuda_getCurrentRawStream
         with torch.cuda.device(self.device):
             nat.check(self._L.gw_create(C.byref(cfg), C.byref(self._h)))
+            self._hv = self._h.value or 0
             n = self.num_envs
             self._obs = torch.empty(n, dtype=torch.int32, device=self.device)
             self._rew = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -250,15 +255,32 @@ class VecCounterTrafficEnv(BaseEnv):
         (torch tensors on the env's GPU are used in place).  Returns
         ``(obs int32[N], reward float32[N], done uint8[N], info)``; an action outside the action
         space flags its env (``check()`` raises) and leaves that env untouched."""
-        torch = _torch()
-        dev = self._checked(action["device"], "device")
-        dur = self._checked(action["duration"], "duration")
-        obs, rew, done = self._outputs()
-        idx = self._dev_index
-        if torch._C._cuda_getDevice() == idx:                  # the one-process-per-GPU case: no context switch
-            rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
-                                 done.data_ptr(), torch._C._cuda_getCurrentRawStream(idx))
+        # (this method is enqueued ~200 000 times a second: the common path -- pre-staged int32 tensors on this GPU, reused
+        #  output buffers, the caller on this env's device -- is written out flat, without helper calls)
+        dev = action["device"]
+        dur = action["duration"]
+        seen = self._seen
+        hit = seen.get(id(dev))
+        if hit is None or hit() is not dev:
+            dev = self._checked(dev, "device")
+        hit = seen.get(id(dur))
+        if hit is None or hit() is not dur:
+            dur = self._checked(dur, "duration")
+        if self._reuse:
+            obs, rew, done = self._obs, self._rew, self._done
         else:
+            obs, rew, done = self._outputs()
+        idx = self._dev_index
+        if self._cuda_get_device() == idx:                     # the one-process-per-GPU case: no context switch
+            fast = self._fast                                   # CPython fast-call shim (csrc/gw_pyfast.c) when built
+            if fast is not None:
+                rc = fast.step(self._hv, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                               done.data_ptr(), self._cuda_raw_stream(idx))
+            else:
+                rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                                     done.data_ptr(), self._cuda_raw_stream(idx))
+        else:
+            torch = _torch()
             with torch.cuda.device(self.device):
                 rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
                                      done.data_ptr(), self._stream())
@@ -310,6 +332,7 @@ class VecCounterTrafficEnv(BaseEnv):
         if getattr(self, "_h", None) is not None and self._h:
             self._L.gw_destroy(self._h)
             self._h = C.c_void_p()
+            self._hv = 0
 
     def __del__(self):
         try:

@@ -88,8 +88,14 @@ class VecInvertedPendulumEnv(BaseEnv):
         dur = net._checked(action["duration"], "duration")
         idx = net._dev_index
         if torch._C._cuda_getDevice() == idx:                  # the one-process-per-GPU case: no context switch
-            rc = net._L.gw_pendulum_step(net._h, self.plant._h, dev.data_ptr(), dur.data_ptr(), self._out_ptrs[0],
-                                         self._out_ptrs[1], self._out_ptrs[2], torch._C._cuda_getCurrentRawStream(idx))
+            fast = net._fast
+            if fast is not None:
+                rc = fast.pendulum_step(net._h.value or 0, self.plant._h.value or 0, dev.data_ptr(), dur.data_ptr(),
+                                        self._out_ptrs[0], self._out_ptrs[1], self._out_ptrs[2],
+                                        torch._C._cuda_getCurrentRawStream(idx))
+            else:
+                rc = net._L.gw_pendulum_step(net._h, self.plant._h, dev.data_ptr(), dur.data_ptr(), self._out_ptrs[0],
+                                             self._out_ptrs[1], self._out_ptrs[2], torch._C._cuda_getCurrentRawStream(idx))
         else:
             with torch.cuda.device(self.device):
                 rc = net._L.gw_pendulum_step(net._h, self.plant._h, dev.data_ptr(), dur.data_ptr(), self._out_ptrs[0],

@@ -244,3 +244,19 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
         assert sizes and len(sizes) == len(names), src
         bad = [(n, int(s)) for n, s in zip(names, sizes) if int(s) != 0]
         assert not bad, "%s: kernels with scratch memory: %s" % (src, bad)
+
+
+def test_fastcall_shim_reaches_the_same_entry_points():
+    """csrc/gw_pyfast.c: the CPython shim env.step() uses instead of ctypes calls the library's own gw_step /
+    gw_pendulum_step (argument validation answers without a GPU) and rejects malformed calls with a Python error."""
+    from gymwipe_amd import _native as nat
+    f = nat.fast()
+    assert f is not None, "gymwipe_amd/lib/_gw_fast.so missing: make -C gymwipe_amd/csrc"
+    L = nat.lib()
+    assert f.step(0, 1, 1, 1, 1, 1, 0) == nat.EINVAL == L.gw_step(None, 1, 1, 1, 1, 1, None)
+    assert b"env is NULL" in L.gw_last_error()
+    assert f.pendulum_step(0, 0, 1, 1, 1, 1, 1, 0) == L.gw_pendulum_step(None, None, 1, 1, 1, 1, 1, None) != nat.OK
+    with pytest.raises(TypeError):
+        f.step(0, 1, 1)
+    with pytest.raises((TypeError, OverflowError)):
+        f.step(0, 1, 1, 1, 1, "x", 0)

@@ -61,6 +61,21 @@ for N in (64, 65536):
         torch.cuda.synchronize()
         best_c = min(best_c, (t1 - t0) / 20)
     out["N=%d" % N]["c_abi_enqueue_us_per_step"] = best_c * 1e6
+    # (d) the same through the CPython fast-call shim (what env.step() uses when it is built)
+    f = env._fast
+    if f is not None:
+        hv = h.value
+        best_f = 1e9
+        for rep in range(20):
+            env.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(5, 25):
+                f.step(hv, ptrs[i][0], ptrs[i][1], o, r, d, stream)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            best_f = min(best_f, (t1 - t0) / 20)
+        out["N=%d" % N]["fastcall_enqueue_us_per_step"] = best_f * 1e6
     env.close()
 t0 = time.perf_counter()
 for _ in range(1000):

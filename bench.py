@@ -185,18 +185,22 @@ def main():
     # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
     from gymwipe_amd.sharding import ChunkedFeedbackGather, ObservationGather, StepRecord
     pipe = None
+    # steps per all-gather: 64 for long timed regions; a short region (the driver's 20 steps) gathers every 16 steps, so that
+    # most of its feedback travels while the region is still stepping and the flush at its end -- whose latency no later
+    # step can hide -- carries only the last few rows
+    GATHER_EVERY = RESET_EVERY if args.steps >= 2 * RESET_EVERY else max(1, min(16, args.steps))
     if world > 1 and not args.no_gather:
         if backend == "nccl":
-            pipe = ChunkedFeedbackGather(N, dev_t, env.pack_feedback, world, chunk=RESET_EVERY)
+            pipe = ChunkedFeedbackGather(N, dev_t, env.pack_feedback, world, chunk=GATHER_EVERY)
         else:                                                    # rehearsal: pack on the GPU, gather on the host
-            stage = torch.empty((RESET_EVERY, N), dtype=torch.uint8, device=dev_t)
+            stage = torch.empty((GATHER_EVERY, N), dtype=torch.uint8, device=dev_t)
 
             def pack_to_host(o, r, d, out):
                 env.pack_feedback(o, r, d, stage[:o.shape[0]])
                 out.copy_(stage[:o.shape[0]])
-            pipe = ChunkedFeedbackGather(N, dev_t, pack_to_host, world, chunk=RESET_EVERY)
-            pipe.packed = [torch.zeros((RESET_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
-            pipe.gathered = [torch.zeros((world, RESET_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
+            pipe = ChunkedFeedbackGather(N, dev_t, pack_to_host, world, chunk=GATHER_EVERY)
+            pipe.packed = [torch.zeros((GATHER_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
+            pipe.gathered = [torch.zeros((world, GATHER_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
     rec = StepRecord(N, dev_t)
     env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
 
@@ -219,6 +223,8 @@ def main():
         """reset -> W warm-up steps -> K timed steps; returns (wall s, stream s, stats delta or None)."""
         for i in range(W):
             one(i)
+        if pipe is not None:
+            pipe.drain()                              # the warm-up steps' feedback leaves before the clock starts
         s0 = env.stats() if with_stats else None   # (synchronises)
         if world > 1:
             dist.barrier()
@@ -389,7 +395,7 @@ def main():
                 "bytes_per_rank_per_step": rec.nbytes,
                 "what": "one all_gather_into_tensor of the 9*N-byte step record per env.step(), issued on the step's stream "
                         "(every rank sees every observation before the next step); the headline uses the chunked form "
-                        "(1 byte per env-step, one all-gather per %d steps, overlapped)" % RESET_EVERY}
+                        "(1 byte per env-step, one all-gather per %d steps, overlapped)" % GATHER_EVERY}
 
     per_step = guarded(secondary_per_step_gather) if (world > 1 and not args.no_gather) else None
     roll = guarded(secondary_rollout) if not args.no_rollout else None
@@ -451,8 +457,9 @@ def main():
                        "actions": "counter-based generator, seed %d (gymwipe_amd/actions.py), identical for the CPU baseline" % SEED,
                        "obs_gather": pipe is not None,
                        "parallelism": "independent env shards, one process per GPU; only exchange: end-of-step feedback "
-                                      "gather, 1 byte per env-step, one RCCL all-gather per %d steps overlapped with stepping"
-                                      % RESET_EVERY,
+                                      "gather, 1 byte per env-step, one RCCL all-gather per %d steps overlapped with stepping "
+                                      "(the warm-up's rows are flushed before the clock starts, the last rows' gather ends inside the timed region)"
+                                      % GATHER_EVERY,
                        "launches_per_step": 1, "stream_ms_per_step": kern_avg_s * 1e3},
             "roofline": roof,
         }

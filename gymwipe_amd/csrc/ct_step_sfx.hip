@@ -185,6 +185,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     if (!FAST) { PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide); }
     PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit); PIN_V(inv_interval);
     PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i); PIN_S(fast_ticks);
+    if (FEEDBACK) { PIN_S(obs); PIN_S(reward); PIN_S(done); }   // the output pointers too (the kernel's only arguments that are not preloaded)
     __builtin_amdgcn_sched_barrier(0);
 
     // (the action is used unconditionally here, so that its loads stay at the top with the others: with every use inside
@@ -468,33 +469,53 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     STAMP(12);
 }
 
-// The leading arguments repeat what the step needs before anything else (the addresses of its first loads and the env
-// count that clamps them): as leading scalar arguments they are PRELOADED into SGPRs by the command processor
-// (-amdgpu-kernarg-preload-count, Makefile; 14 dwords at most), so the table and state loads issue in the wave's first
-// cycles.  Read from the GwState in the kernel-argument segment they cost two scalar-cache round trips (an s_load batch
-// for the table address and the block size, another for the state addresses) before the first vector load could leave.
-// The rest of the 1.2 KB of arguments is fetched under the shadow of those loads.  The tables sit gw_blob_header(D)
-// bytes before the `ip` records (gw_api.cpp), which saves their pointer.
+// The kernel's arguments: only what changes per call and the addresses of the wave's first loads -- under 100 bytes.
+// Everything else (the handle's GwDevConst and GwState, the tables) sits in the header of the `ip` allocation
+// (gw_internal.h: gw_blob_header) and is read from there by scalar loads.
+//  * As leading scalar arguments the seven values below are PRELOADED into SGPRs by the command processor
+//    (-amdgpu-kernarg-preload-count, Makefile; 14 dwords at most), so the table and state loads issue in the wave's first
+//    cycles; read from a GwState in the kernel-argument segment they cost two scalar-cache round trips before the first
+//    vector load could leave.  The constants are fetched under the shadow of those loads.
+//  * On the host, a launch with both structs by value (1.2 KB) spent 3.6 us of its 5.5 us writing arguments into
+//    device-visible memory (tools/launch_floor.hip); the short block takes env.step()'s enqueue below the kernel's time
+//    in every phase.
 #define GW_LEAD_PARAMS uint32_t* __restrict__ ip, double* __restrict__ tw, uint32_t* __restrict__ tk, uint8_t* __restrict__ qb, \
-                       const int32_t* __restrict__ device, const int32_t* __restrict__ duration, uint32_t n_envs
-#define GW_LEAD_ARGS(st_) (st_).ip, (st_).tw, (st_).tk, (st_).qb, device, duration, (uint32_t)(st_).N
+                       const int32_t* __restrict__ device, const int32_t* __restrict__ duration, uint32_t n_envs, int32_t n_dev
+#define GW_LEAD_ARGS(st_) (st_).ip, (st_).tw, (st_).tk, (st_).qb, device, duration, (uint32_t)(st_).N, (int32_t)(st_).D
+// (read through the CONSTANT address space: nothing writes the header while a step kernel runs, and as constant-space
+//  loads the reads become scalar loads that the compiler may issue anywhere -- in particular at the top of the wave,
+//  in front of the fence that follows the table staging; as plain global loads they stayed behind that fence and their
+//  latency was exposed after the tables had landed)
+// (the host pass of the compiler parses these device functions too and has no address spaces: plain types there)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GW_AS_CONST __attribute__((address_space(4)))
+#else
+#define GW_AS_CONST
+#endif
 template <int DT>
-__device__ __forceinline__ GwState with_lead(const GwState& st_arg, const GwDevConst& c, uint32_t* ip, double* tw, uint32_t* tk,
-                                             uint8_t* qb, uint32_t n_envs)
+__device__ __forceinline__ GwDevConst hdr_const(const uint32_t* ip, int n_dev)
 {
-    GwState st = st_arg;
-    st.ip = ip; st.tw = tw; st.tk = tk; st.qb = qb; st.N = (int64_t)n_envs;
-    st.blob = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(DT > 0 ? DT : c.D);
+    const int D = DT > 0 ? DT : n_dev;
+    const uint8_t* at = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(D) + gw_hdr_cst_off(D);
+    return *(const GW_AS_CONST GwDevConst*)at;                                   // (only the fields the body uses are loaded)
+}
+template <int DT>
+__device__ __forceinline__ GwState hdr_state(uint32_t* ip, double* tw, uint32_t* tk, uint8_t* qb, uint32_t n_envs, int n_dev)
+{
+    const int D = DT > 0 ? DT : n_dev;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(D);
+    GwState st = *(const GW_AS_CONST GwState*)(base + gw_hdr_st_off(D));
+    st.ip = ip; st.tw = tw; st.tk = tk; st.qb = qb; st.N = (int64_t)n_envs; st.D = D;
+    st.blob = base;
     return st;
 }
 
 template <int DT, int MODE>
-__global__ __launch_bounds__(64) void ct_step_sfx_kernel(GW_LEAD_PARAMS, GwState st_arg, GwDevConst c,
-                                                        int32_t* __restrict__ obs,
-                                                        float* __restrict__ reward,
+__global__ __launch_bounds__(64) void ct_step_sfx_kernel(GW_LEAD_PARAMS, int32_t* __restrict__ obs, float* __restrict__ reward,
                                                         uint8_t* __restrict__ done)
 {
-    const GwState st = with_lead<DT>(st_arg, c, ip, tw, tk, qb, n_envs);
+    const GwState st = hdr_state<DT>(ip, tw, tk, qb, n_envs, n_dev);
+    const GwDevConst c = hdr_const<DT>(ip, n_dev);
     double now_new;
     bool live;
     ct_step_sfx_body<DT, true, MODE>(st, c, device, duration, obs, reward, done, now_new, live);
@@ -509,11 +530,12 @@ __global__ __launch_bounds__(64) void ct_step_sfx_kernel(GW_LEAD_PARAMS, GwState
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 template <int MODE, bool HALF>
-__global__ __launch_bounds__(64) void pend_step_kernel(GW_LEAD_PARAMS, GwState st_arg, GwDevConst c, GwPlantDev p,
+__global__ __launch_bounds__(64) void pend_step_kernel(GW_LEAD_PARAMS, GwPlantDev p,
                                                        int32_t* __restrict__ obs, float* __restrict__ reward,
                                                        double* __restrict__ angle_deg)
 {
-    const GwState st = with_lead<2>(st_arg, c, ip, tw, tk, qb, n_envs);
+    const GwState st = hdr_state<2>(ip, tw, tk, qb, n_envs, n_dev);
+    const GwDevConst c = hdr_const<2>(ip, n_dev);
     constexpr int EPW = HALF ? 32 : 64;                  // envs per wave
     constexpr int NR = EPW / 16;                         // matrix-core rounds of 16 envs each
     __shared__ double s_x[EPW][5];                       // [env of the wave][component], padded: conflict-free both ways
@@ -704,7 +726,7 @@ int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, cons
     // the host can rule out that any env reaches their validity limits in this launch, without the per-lane limit tests
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
 #define GW_STEP(MODE_) hipLaunchKernelGGL((ct_step_sfx_kernel<DT, MODE_>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, GW_LEAD_ARGS(st), \
-                                          st, cst, obs, reward, done)
+                                          obs, reward, done)
     switch (fast ? (below_limits ? 2 : 1) : 0) {
     case 2:  GW_STEP(2); break;
     case 1:  GW_STEP(1); break;
@@ -769,7 +791,7 @@ int gw_launch_pend_step(const GwState& st, const GwDevConst& cst, const GwPlantD
     const unsigned grid = (unsigned)((st.N + (half ? 31 : 63)) / (half ? 32 : 64));
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
     const int mode = fast ? (below_limits ? 2 : 1) : 0;
-#define GW_PEND(MODE_, HALF_) hipLaunchKernelGGL((pend_step_kernel<MODE_, HALF_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, GW_LEAD_ARGS(st), st, cst, p, obs, reward, angle_deg)
+#define GW_PEND(MODE_, HALF_) hipLaunchKernelGGL((pend_step_kernel<MODE_, HALF_>), dim3(grid), dim3(64), 0, (hipStream_t)stream, GW_LEAD_ARGS(st), p, obs, reward, angle_deg)
     if (half) { if (mode == 2) GW_PEND(2, true); else if (mode == 1) GW_PEND(1, true); else GW_PEND(0, true); }
     else      { if (mode == 2) GW_PEND(2, false); else if (mode == 1) GW_PEND(1, false); else GW_PEND(0, false); }
 #undef GW_PEND

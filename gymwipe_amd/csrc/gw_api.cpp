@@ -513,6 +513,10 @@ int gw_create(const gw_config* cfg, gw_env** out)
         HIP_TRY_D(hipMemcpy(d_pos, pos.data(), pos.size() * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY_D(hipMemcpy(d_extra, ext.data(), ext.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    if (st.ip) {                                    // the per-step kernels read both structs from the header of the ip block
+        HIP_TRY_D(hipMemcpy(d_blob + gw_hdr_cst_off(D), &k, sizeof k, hipMemcpyHostToDevice));
+        HIP_TRY_D(hipMemcpy(d_blob + gw_hdr_st_off(D), &st, sizeof st, hipMemcpyHostToDevice));
+    }
     rc = explicit_q ? gw_launch_init(st, nullptr) : gw_launch_init_sfx(st, nullptr);
     if (!rc && env->dyn) rc = gw_launch_init_dyn(st, k, env->tab.thermal, nullptr);
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }

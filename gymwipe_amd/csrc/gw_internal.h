@@ -107,13 +107,20 @@ struct GwBlobLayout {
           total(h2 + D * D * GW_MAX_NSTATES) {}
 };
 
-// In the default (suffix-queue) mode the blob lives in the SAME allocation as the `ip` records, gw_blob_header(D) bytes
-// before them: the step kernel gets `ip` as a preloaded leading argument and derives the tables' address from it
-// (one pointer fewer among the 14 argument dwords the command processor can hand to a wave in SGPRs).
+// In the default (suffix-queue) mode the step tables, the handle's GwDevConst and its GwState live in the SAME allocation as
+// the `ip` records, in a header of gw_blob_header(D) bytes in front of them (gw_api.cpp fills it at gw_create):
+//     [ blob (GwBlobLayout) | GwDevConst at gw_hdr_cst_off | GwState at gw_hdr_st_off | pad to 256 ] [ ip records ... ]
+// The per-step kernels get `ip` as a preloaded leading argument and derive everything else from it.  Their argument block
+// shrinks from 1.2 KB (both structs by value) to under 100 bytes: the runtime writes a launch's arguments into
+// device-visible memory, and for 1.2 KB that alone took 3.6 us of the host's 5.5 us per launch (tools/launch_floor.hip).
 #if defined(__HIPCC__)
-__host__ __device__
+#define GW_HDC __host__ __device__
+#else
+#define GW_HDC
 #endif
-constexpr int gw_blob_header(int D) { return (GwBlobLayout(D).total + 16 + 255) / 256 * 256; }
+GW_HDC constexpr int gw_hdr_cst_off(int D) { return (GwBlobLayout(D).total + 16 + 15) / 16 * 16; }
+GW_HDC constexpr int gw_hdr_st_off(int D) { return gw_hdr_cst_off(D) + ((int)sizeof(GwDevConst) + 15) / 16 * 16; }
+GW_HDC constexpr int gw_blob_header(int D) { return (gw_hdr_st_off(D) + (int)sizeof(GwState) + 255) / 256 * 256; }
 
 // decode certainty of a link in a given noise state (host: gw_tables.cpp; valid while t < fmod_limit)
 enum { GW_CLS_COMPUTE = 0, GW_CLS_OK = 1, GW_CLS_HDR_FAIL = 2, GW_CLS_PAY_FAIL = 3 };

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <ctime>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 __global__ __launch_bounds__(64) void k_empty() {}
@@ -44,6 +46,31 @@ __global__ __launch_bounds__(64) void k_spin_mem_pol(unsigned long long cycles, 
     if (MODE == 1) ST4("nt");
     if (MODE == 2) ST4("sc1");
     if (MODE == 3) ST4("sc0 sc1");
+}
+
+// host-side enqueue cost: a kernel with the step kernel's argument block (7 leading scalars + 1.2 KB of structs + 3 pointers)
+struct Big { char b[1176]; };
+__global__ __launch_bounds__(64) void k_args(unsigned* a, double* b, unsigned* c, unsigned char* d, const int* e, const int* f, unsigned n,
+                                             Big big, int* o, float* r, unsigned char* dn)
+{
+    if (n == 0xffffffffu && a) a[0] = (unsigned)big.b[17];
+}
+
+template <class F> double enqueue_us(F launch, int n, hipStream_t s)
+{
+    for (int i = 0; i < 200; ++i) launch();
+    CK(hipStreamSynchronize(s));
+    double best = 1e30;
+    for (int rep = 0; rep < 7; ++rep) {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < n; ++i) launch();
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        CK(hipStreamSynchronize(s));
+        const double us = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) * 1e-3 / n;
+        if (us < best) best = us;
+    }
+    return best;
 }
 
 template <class F> double per_launch_us(F launch, int n, hipStream_t s)
@@ -90,6 +117,28 @@ int main(int argc, char** argv)
     printf(" | sc0 sc1 %.2f us/launch\n", per_launch_us([&] { hipLaunchKernelGGL(k_spin_mem_pol<3>, dim3(1024), dim3(64), 0, s, 12500ull, (u32x4*)a, 4); }, n, s));
     printf("   all waves spin 12500:  plain %.2f", per_launch_us([&] { hipLaunchKernelGGL(k_spin_mem, dim3(1024), dim3(64), 0, s, 12500ull, a, 4); }, n, s));
     printf("\n");
+    {   // host enqueue cost per launch (clock stopped before the synchronize; 64 launches so that the queue never fills)
+        Big big; memset(&big, 1, sizeof big);
+        unsigned* pa = (unsigned*)a;
+        const double t_chevron = enqueue_us([&] { hipLaunchKernelGGL(k_args, dim3(1024), dim3(64), 0, s, pa, (double*)a, pa, (unsigned char*)a,
+                                                                     (const int*)a, (const int*)a, 65536u, big, (int*)a, (float*)a, (unsigned char*)a); }, 64, s);
+        const double t_empty = enqueue_us([&] { hipLaunchKernelGGL(k_empty, dim3(1024), dim3(64), 0, s); }, 64, s);
+        // the same kernel through hipModuleLaunchKernel with ONE pre-built argument buffer
+        hipFunction_t fn = nullptr;
+        double t_mod = -1;
+        if (hipGetFuncBySymbol(&fn, (const void*)k_args) == hipSuccess && fn) {
+            struct __attribute__((packed, aligned(8))) Args { unsigned* a; double* b; unsigned* c; unsigned char* d; const int* e; const int* f; unsigned n; unsigned pad; Big big; int* o; float* r; unsigned char* dn; } ab;
+            memset(&ab, 0, sizeof ab);
+            ab.a = pa; ab.b = (double*)a; ab.c = pa; ab.d = (unsigned char*)a; ab.e = (const int*)a; ab.f = (const int*)a; ab.n = 65536u; ab.big = big;
+            ab.o = (int*)a; ab.r = (float*)a; ab.dn = (unsigned char*)a;
+            size_t sz = sizeof ab;
+            void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ab, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            t_mod = enqueue_us([&] { (void)hipModuleLaunchKernel(fn, 1024, 1, 1, 64, 1, 1, 0, s, nullptr, extra); }, 64, s);
+            CK(hipGetLastError());
+        }
+        printf("host enqueue per launch: empty kernel %.2f us | 11 arguments, 1.2 KB, <<<>>> %.2f us | same through hipModuleLaunchKernel + one buffer %.2f us\n",
+               t_empty, t_chevron, t_mod);
+    }
     // the counter's rate: cycles per microsecond (spin a long while, time it)
     {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -56,6 +56,13 @@ __global__ __launch_bounds__(64) void k_args(unsigned* a, double* b, unsigned* c
     if (n == 0xffffffffu && a) a[0] = (unsigned)big.b[17];
 }
 
+__global__ __launch_bounds__(64) void k_small(unsigned* a, double* b, unsigned* c, unsigned char* d, const int* e, const int* f, unsigned n, int nd,
+                                              int* o, float* r, unsigned char* dn)
+{
+    if (n == 0xffffffffu && a) a[0] = (unsigned)nd;
+}
+__global__ __launch_bounds__(64) void k_one(unsigned* a) { if (a == (unsigned*)1) a[0] = 0; }
+
 template <class F> double enqueue_us(F launch, int n, hipStream_t s)
 {
     for (int i = 0; i < 200; ++i) launch();
@@ -136,8 +143,21 @@ int main(int argc, char** argv)
             t_mod = enqueue_us([&] { (void)hipModuleLaunchKernel(fn, 1024, 1, 1, 64, 1, 1, 0, s, nullptr, extra); }, 64, s);
             CK(hipGetLastError());
         }
+        const double t_small = enqueue_us([&] { hipLaunchKernelGGL(k_small, dim3(1024), dim3(64), 0, s, pa, (double*)a, pa, (unsigned char*)a,
+                                                                   (const int*)a, (const int*)a, 65536u, 4, (int*)a, (float*)a, (unsigned char*)a); }, 64, s);
+        const double t_one = enqueue_us([&] { hipLaunchKernelGGL(k_one, dim3(1024), dim3(64), 0, s, pa); }, 64, s);
+        printf("host enqueue per launch: one pointer argument %.2f us | 11 scalar arguments (80 B) %.2f us\n", t_one, t_small);
         printf("host enqueue per launch: empty kernel %.2f us | 11 arguments, 1.2 KB, <<<>>> %.2f us | same through hipModuleLaunchKernel + one buffer %.2f us\n",
                t_empty, t_chevron, t_mod);
+    }
+    {   // the small runtime calls gw_step makes around its launch
+        auto t = [&](auto f) { timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0); for (int i = 0; i < 100000; ++i) f();
+                               clock_gettime(CLOCK_MONOTONIC, &t1); return ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / 100000.0; };
+        hipStreamCaptureStatus cs;
+        int dev = 0;
+        printf("ns per call: hipSetDevice %.0f | hipGetDevice %.0f | hipStreamIsCapturing %.0f | hipGetLastError %.0f\n",
+               t([&] { (void)hipSetDevice(0); }), t([&] { (void)hipGetDevice(&dev); }), t([&] { (void)hipStreamIsCapturing(s, &cs); }),
+               t([&] { (void)hipGetLastError(); }));
     }
     // the counter's rate: cycles per microsecond (spin a long while, time it)
     {

@@ -122,8 +122,10 @@ def build(force=False, quiet=True):
     """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
             if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(_PKG, "..", "include", "gymwipe_amd.h")]
-    stale = (not os.path.exists(LIB_PATH)
-             or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+    shim = os.path.join(os.path.dirname(LIB_PATH), "_gw_fast.so")            # CPython fast-call shim, same Makefile
+    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(shim)
+             or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+             or os.path.getmtime(os.path.join(CSRC, "gw_pyfast.c")) > os.path.getmtime(shim))
     if force or stale:
         cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)

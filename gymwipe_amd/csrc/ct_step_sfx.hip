@@ -326,12 +326,29 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 len_d = gw_len_after_ticks(len_d, kk, mult_d, kd);
             };
 
+            // the same in one jump (gw_fastmath.h: a floor division corrected by the exact FMA residual; exact, validated at
+            // gw_create) wherever its preconditions hold, else by the loop above.  A data packet of the first steps after a
+            // reset lasts 2-4 ms = 2-4 ticks: the loop then often needs a second pass, the jump never does (-2 % per step).
+            auto ticks_upto = [&](double t, bool inclusive) {
+                uint32_t nj = 0;
+                double wj = wake;
+                bool tiej = false;
+                if ((FAST || fast_ticks) && gw_tick_jump(wake, t, interval, inv_interval, inclusive, &nj, &wj, &tiej)) {
+                    wake = wj;
+                    tau += nj;
+                    if (tiej) fl |= GW_FLAG_TIE;
+                    len_d = gw_len_after_ticks(len_d, nj, mult_d, kd);
+                } else {
+                    ticks_to(t, inclusive);
+                }
+            };
+
             if (granted) {
                 const double total = (double)slots * slot;               // simple_stack.py:400
                 const double stopw = t_r + total;                        // :401 (== timeout time :406)
                 double cur = t_r;
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
-                ticks_to(cur, false);
+                ticks_to(cur, false);                                    // (0 or 1 tick here: the loop's single pass is cheaper than the jump)
                 for (;;) {
                     if (len_d == 0) {                                     // :409-416
                         // (a silent sender, mult 0, never signals packet-added: the MAC waits for the timeout)
@@ -368,7 +385,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                     rvm |= ok ? (1u << d) : 0u;
                     dn = (ok && pv == cbound) ? 1u : dn;
                     fl |= !(x.t_e < t_end) ? (uint32_t)GW_FLAG_CARRY : 0u;
-                    ticks_to(x.t_e, true);                                // ticks are older events than the MAC's resume
+                    ticks_upto(x.t_e, true);                              // ticks are older events than the MAC's resume
                     cur = x.t_e;
                     if (!(cur < stopw)) break;                            // window timeout already processed
                 }
@@ -377,19 +394,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             STAMP(7);
             // ---- A.5: remaining ticks up to the end of the step: up to 21 of them, counted in one jump
             //      (gw_fastmath.h; exact, validated at gw_create) or, where the jump declines, by the loop --------
-            {
-                uint32_t nj = 0;
-                double wj = wake;
-                bool tiej = false;
-                if ((FAST || fast_ticks) && gw_tick_jump(wake, t_end, interval, inv_interval, true, &nj, &wj, &tiej)) {
-                    wake = wj;
-                    tau += nj;
-                    if (tiej) fl |= GW_FLAG_TIE;
-                    len_d = gw_len_after_ticks(len_d, nj, mult_d, kd);
-                } else {
-                    ticks_to(t_end, true);
-                }
-            }
+            ticks_upto(t_end, true);
             STAMP(8);
             const uint32_t n_ticks = tau - tau0;
             k.app += kd.app;

@@ -171,7 +171,15 @@ def main():
         local = local % ndev
     torch.cuda.set_device(local)
     dev_t = torch.device("cuda", local)
-    if world > 1:
+    # GW_BENCH_FORCE_GATHER=1 (tests): run the N > 1 code path -- process group, chunked gather over RCCL, per-step gather --
+    # with a single rank, so that a one-GPU box exercises every collective call the multi-GPU runs make
+    multi = world > 1 or bool(os.environ.get("GW_BENCH_FORCE_GATHER"))
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev_t)
         else:
@@ -189,7 +197,7 @@ def main():
     # most of its feedback travels while the region is still stepping and the flush at its end -- whose latency no later
     # step can hide -- carries only the last few rows
     GATHER_EVERY = RESET_EVERY if args.steps >= 2 * RESET_EVERY else max(1, min(16, args.steps))
-    if world > 1 and not args.no_gather:
+    if multi and not args.no_gather:
         if backend == "nccl":
             pipe = ChunkedFeedbackGather(N, dev_t, env.pack_feedback, world, chunk=GATHER_EVERY)
         else:                                                    # rehearsal: pack on the GPU, gather on the host
@@ -226,7 +234,7 @@ def main():
         if pipe is not None:
             pipe.drain()                              # the warm-up steps' feedback leaves before the clock starts
         s0 = env.stats() if with_stats else None   # (synchronises)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -238,7 +246,7 @@ def main():
             pipe.drain()                              # the job is done when the last gather has landed
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             dist.barrier()
         stream_s = ev[0].elapsed_time(ev[1]) * 1e-3
         delta = None
@@ -251,7 +259,7 @@ def main():
     window(False)
     cal_wall, cal_stream, _ = window(False)
     cal = torch.tensor([cal_stream, cal_wall], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(cal, op=dist.ReduceOp.MAX)
     cal_stream, cal_wall = float(cal[0]), float(cal[1])
     if args.repeats > 0:
@@ -274,7 +282,7 @@ def main():
 
     # the job's time per window is the slowest rank's
     t = torch.tensor(walls, dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     walls_max = t.cpu().tolist()
     wall_total = sum(walls_max)
@@ -397,11 +405,11 @@ def main():
                         "(every rank sees every observation before the next step); the headline uses the chunked form "
                         "(1 byte per env-step, one all-gather per %d steps, overlapped)" % GATHER_EVERY}
 
-    per_step = guarded(secondary_per_step_gather) if (world > 1 and not args.no_gather) else None
+    per_step = guarded(secondary_per_step_gather) if (multi and not args.no_gather) else None
     roll = guarded(secondary_rollout) if not args.no_rollout else None
     # graph replay at N = 1 only: stream capture next to a live RCCL communicator (whose watchdog thread queries
     # events) is a needless risk for a secondary figure
-    graph_sec = guarded(secondary_graph) if (not args.no_graph and world == 1 and (W + K) % RESET_EVERY == 0) else None
+    graph_sec = guarded(secondary_graph) if (not args.no_graph and not multi and (W + K) % RESET_EVERY == 0) else None
     steady = guarded(secondary_steady) if not args.no_steady else None
 
     if rank == 0:
@@ -475,7 +483,7 @@ def main():
             cs = args.cpu_seconds
             out["cpu_baseline"] = cpu_baseline(D, W, K, cs, min(2.5, cs / 4), other_seconds=min(2.0, cs / 5))
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

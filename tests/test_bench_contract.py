@@ -53,3 +53,21 @@ def test_bench_config4_prints_a_contract_line_with_one_launch_per_step():
     assert r["bound"] == "hbm" and r["launches_per_step"] == 1 and r["kernel"] == "pend_step_kernel"
     assert r["mfma"]["instruction"] == "v_mfma_f64_16x16x4_f64" and 5 < r["mfma"]["plant_substeps_per_env_step"] < 15
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_runs_on_rccl_with_one_rank():
+    """GW_BENCH_FORCE_GATHER=1: the N > 1 path of bench.py (process group on RCCL, chunked feedback gather every 16 steps with
+    the warm-up flush and the end-of-region drain, the per-step observation gather) with a single rank -- every collective call
+    the driver's multi-GPU runs make, on the one GPU this box has."""
+    env = dict(os.environ, GW_BENCH_FORCE_GATHER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--envs", "8192", "--repeats", "30", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["config"]["obs_gather"] is True and "per 16 steps" in d["config"]["parallelism"]
+    assert "error" not in d["per_step_gather"], d["per_step_gather"]
+    assert d["per_step_gather"]["bytes_per_rank_per_step"] == 9 * 8192 and d["value"] > 1e6

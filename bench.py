@@ -199,7 +199,8 @@ def main():
     GATHER_EVERY = RESET_EVERY if args.steps >= 2 * RESET_EVERY else max(1, min(16, args.steps))
     if multi and not args.no_gather:
         if backend == "nccl":
-            pipe = ChunkedFeedbackGather(N, dev_t, env.pack_feedback, world, chunk=GATHER_EVERY)
+            # pack=None: the step kernel writes each step's one-byte row itself (gw_step_fb), no packing launch per chunk
+            pipe = ChunkedFeedbackGather(N, dev_t, None, world, chunk=GATHER_EVERY)
         else:                                                    # rehearsal: pack on the GPU, gather on the host
             stage = torch.empty((GATHER_EVERY, N), dtype=torch.uint8, device=dev_t)
 
@@ -219,6 +220,8 @@ def main():
     def one(i):
         if pipe is not None:                      # this step's outputs go into the current chunk record
             env._obs, env._rew, env._done = pipe.slot()
+            if pipe._pack is None:
+                env._fb = pipe.byte_slot()
         if i % RESET_EVERY == 0:
             env.reset()                           # (its observation lands in the slot the step then overwrites)
         env.step(acts[i])
@@ -279,6 +282,7 @@ def main():
         if delta is not None:
             deltas.append(delta)
     env.check()
+    env._fb = None                                   # (the secondaries below step without the gather's byte rows)
 
     # the job's time per window is the slowest rank's
     t = torch.tensor(walls, dtype=torch.float64, device=red_dev)

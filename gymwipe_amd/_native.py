@@ -27,7 +27,7 @@ CFG_PER_ENV_GEOMETRY = 32
 
 EXPORTS = (
     "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
-    "gw_destroy", "gw_reset", "gw_step", "gw_rollout", "gw_set_position", "gw_set_positions", "gw_received", "gw_delivered", "gw_enqueue", "gw_pack_feedback", "gw_unpack_feedback", "gw_get_state",
+    "gw_destroy", "gw_reset", "gw_step", "gw_step_fb", "gw_rollout", "gw_set_position", "gw_set_positions", "gw_received", "gw_delivered", "gw_enqueue", "gw_pack_feedback", "gw_unpack_feedback", "gw_get_state",
     "gw_stats_read", "gw_clear_flags", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue", "gw_selftest_runq",
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
@@ -164,6 +164,7 @@ def lib():
     L.gw_destroy.argtypes, L.gw_destroy.restype = [vp], C.c_int
     L.gw_reset.argtypes, L.gw_reset.restype = [vp, vp, vp, vp], C.c_int
     L.gw_step.argtypes, L.gw_step.restype = [vp, vp, vp, vp, vp, vp, vp], C.c_int
+    L.gw_step_fb.argtypes, L.gw_step_fb.restype = [vp, vp, vp, vp, vp, vp, vp, vp], C.c_int
     L.gw_rollout.argtypes, L.gw_rollout.restype = [vp, i32, vp, vp, vp, vp, vp, vp], C.c_int
     L.gw_received.argtypes, L.gw_received.restype = [vp, vp, vp], C.c_int
     L.gw_enqueue.argtypes, L.gw_enqueue.restype = [vp, i32, vp, vp], C.c_int
@@ -233,7 +234,8 @@ def fast():
                 mod = importlib.util.module_from_spec(spec)
                 loader.exec_module(mod)
                 L = lib()
-                mod.bind(C.cast(L.gw_step, C.c_void_p).value, C.cast(L.gw_pendulum_step, C.c_void_p).value)
+                mod.bind(C.cast(L.gw_step, C.c_void_p).value, C.cast(L.gw_pendulum_step, C.c_void_p).value,
+                         C.cast(L.gw_step_fb, C.c_void_p).value)
                 _fast = mod
             except Exception:
                 _fast = None

@@ -99,6 +99,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                                                  int32_t* __restrict__ obs,
                                                  float* __restrict__ reward,
                                                  uint8_t* __restrict__ done,
+                                                 uint8_t* __restrict__ fb,          // one-byte feedback row (gw_step_fb) or null
                                                  double& now_out, bool& live_out)
 {
     constexpr bool PACKED = DT > 0;                      // the byte record is held in registers
@@ -185,7 +186,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     if (!FAST) { PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide); }
     PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit); PIN_V(inv_interval);
     PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i); PIN_S(fast_ticks);
-    if (FEEDBACK) { PIN_S(obs); PIN_S(reward); PIN_S(done); }   // the output pointers too (the kernel's only arguments that are not preloaded)
+    if (FEEDBACK) { PIN_S(obs); PIN_S(reward); PIN_S(done); PIN_S(fb); }   // the output pointers too (the kernel's only arguments that are not preloaded)
     __builtin_amdgcn_sched_barrier(0);
 
     // (the action is used unconditionally here, so that its loads stay at the top with the others: with every use inside
@@ -217,6 +218,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 obs[e] = latest + cbound;
                 reward[e] = 0.0f;
                 done[e] = (uint8_t)dn;
+                if (fb) fb[e] = (uint8_t)((uint32_t)(((latest > 0) - (latest < 0)) + 1) | (10u << 2) | (dn << 7));
             }
         } else {
             const uint32_t bound = (uint32_t)cbound;
@@ -460,6 +462,8 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 st_(obs, e << 2, (int32_t)(latest + cbound));
                 st_(reward, e << 2, (float)r);
                 st_(done, e, (uint8_t)dn);
+                // the same feedback in the exchange format of feedback_pack.hip: bits 0-1 sign(obs - bound) + 1, 2-6 reward + 10, 7 done
+                if (fb) st_(fb, e, (uint8_t)((uint32_t)(((latest > 0) - (latest < 0)) + 1) | ((uint32_t)(r + 10) << 2) | (dn << 7)));
             }
             now_out = t_end;
 
@@ -517,13 +521,13 @@ __device__ __forceinline__ GwState hdr_state(uint32_t* ip, double* tw, uint32_t*
 
 template <int DT, int MODE>
 __global__ __launch_bounds__(64) void ct_step_sfx_kernel(GW_LEAD_PARAMS, int32_t* __restrict__ obs, float* __restrict__ reward,
-                                                        uint8_t* __restrict__ done)
+                                                        uint8_t* __restrict__ done, uint8_t* __restrict__ fb)
 {
     const GwState st = hdr_state<DT>(ip, tw, tk, qb, n_envs, n_dev);
     const GwDevConst c = hdr_const<DT>(ip, n_dev);
     double now_new;
     bool live;
-    ct_step_sfx_body<DT, true, MODE>(st, c, device, duration, obs, reward, done, now_new, live);
+    ct_step_sfx_body<DT, true, MODE>(st, c, device, duration, obs, reward, done, fb, now_new, live);
 }
 
 // ---- BASELINE config 4: env.step() of the pendulum env in ONE launch ------------------------------------------------
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GW_LEAD_PARAMS, GwPlantDe
 
     double now_new;
     bool live;
-    ct_step_sfx_body<2, false, MODE, HALF>(st, c, device, duration, nullptr, nullptr, nullptr, now_new, live);
+    ct_step_sfx_body<2, false, MODE, HALF>(st, c, device, duration, nullptr, nullptr, nullptr, nullptr, now_new, live);
 #ifdef GW_EXP_NO_EPILOGUE
     if (now_new >= 0.0) return;
 #endif
@@ -723,7 +727,7 @@ __global__ void ct_clear_flags_kernel(GwState st)
 
 template <int DT>
 int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
-           int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits)
+           int32_t* obs, float* reward, uint8_t* done, uint8_t* fb, void* stream, bool below_limits)
 {
     const unsigned blk = 64u;                          // the kernel's compile-time block size
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
@@ -731,7 +735,7 @@ int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, cons
     // the host can rule out that any env reaches their validity limits in this launch, without the per-lane limit tests
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
 #define GW_STEP(MODE_) hipLaunchKernelGGL((ct_step_sfx_kernel<DT, MODE_>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, GW_LEAD_ARGS(st), \
-                                          obs, reward, done)
+                                          obs, reward, done, fb)
     switch (fast ? (below_limits ? 2 : 1) : 0) {
     case 2:  GW_STEP(2); break;
     case 1:  GW_STEP(1); break;
@@ -746,17 +750,17 @@ inline int ok_or_ehip() { return hipGetLastError() == hipSuccess ? GW_OK : GW_EH
 } // namespace
 
 int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
-                       int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits)
+                       int32_t* obs, float* reward, uint8_t* done, uint8_t* fb, void* stream, bool below_limits)
 {
     switch (st.D) {
-    case 2:  return launch<2>(st, cst, device, duration, obs, reward, done, stream, below_limits);
-    case 3:  return launch<3>(st, cst, device, duration, obs, reward, done, stream, below_limits);
-    case 4:  return launch<4>(st, cst, device, duration, obs, reward, done, stream, below_limits);
-    case 6:  return launch<6>(st, cst, device, duration, obs, reward, done, stream, below_limits);
-    case 8:  return launch<8>(st, cst, device, duration, obs, reward, done, stream, below_limits);
-    case 16: return launch<16>(st, cst, device, duration, obs, reward, done, stream, below_limits);
-    case 32: return launch<32>(st, cst, device, duration, obs, reward, done, stream, below_limits);
-    default: return launch<0>(st, cst, device, duration, obs, reward, done, stream, below_limits);
+    case 2:  return launch<2>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 3:  return launch<3>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 4:  return launch<4>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 6:  return launch<6>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 8:  return launch<8>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 16: return launch<16>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 32: return launch<32>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    default: return launch<0>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
     }
 }
 

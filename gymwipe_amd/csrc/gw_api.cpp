@@ -96,7 +96,7 @@ int select_device(const gw_env* env)
 }
 
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
-                int32_t* obs, float* reward, uint8_t* done, void* stream);
+                int32_t* obs, float* reward, uint8_t* done, void* stream, uint8_t* fb = nullptr, bool* fb_done = nullptr);
 
 } // namespace
 bool gw_env_below_limits(gw_env* env, void* stream);
@@ -182,13 +182,18 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
     if (getenv("GW_NO_IDEM")) k.idem_states = 0;    // test switch: take the exact-count path although the map is idempotent
 }
 
+// fb: the step's feedback as one byte per env (gw_step_fb), written by the step kernel itself in the default mode;
+// *fb_done tells the caller whether it was (else the caller runs the packing kernel)
 int launch_step(gw_env* env, const int32_t* device, const int32_t* duration,
-                int32_t* obs, float* reward, uint8_t* done, void* stream)
+                int32_t* obs, float* reward, uint8_t* done, void* stream, uint8_t* fb, bool* fb_done)
 {
+    if (fb_done) *fb_done = false;
     if (env->dyn && env->st.tk) return gw_launch_step_dyn(env->st, env->cst_host, device, duration, obs, reward, done, stream);
-    return env->st.tk ? gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, stream,
-                                           gw_env_below_limits(env, stream))
-                      : gw_launch_step(env->st, device, duration, obs, reward, done, stream);
+    if (env->st.tk) {
+        if (fb_done) *fb_done = true;
+        return gw_launch_step_sfx(env->st, env->cst_host, device, duration, obs, reward, done, fb, stream, gw_env_below_limits(env, stream));
+    }
+    return gw_launch_step(env->st, device, duration, obs, reward, done, stream);
 }
 
 // Expand the suffix-encoded queue of one sender into packet byte sizes, head first (gw_queue.h).
@@ -557,6 +562,24 @@ int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
     if (launch_step(env, device_dev, duration_dev, obs_dev, reward_dev, done_dev, stream))
         return fail(GW_EHIP, "step kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     gw_env_add_steps(env, 1);
+    return GW_OK;
+}
+
+int gw_step_fb(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
+               int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* feedback_byte_dev, void* stream)
+{
+    if (!feedback_byte_dev) return gw_step(env, device_dev, duration_dev, obs_dev, reward_dev, done_dev, stream);
+    if (!env) return fail(GW_EINVAL, "env is NULL");
+    if (!device_dev || !duration_dev || !obs_dev || !reward_dev || !done_dev)
+        return fail(GW_EINVAL, "gw_step_fb: NULL device pointer");
+    int rc = select_device(env);
+    if (rc) return rc;
+    bool fused = false;
+    if (launch_step(env, device_dev, duration_dev, obs_dev, reward_dev, done_dev, stream, feedback_byte_dev, &fused))
+        return fail(GW_EHIP, "step kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    gw_env_add_steps(env, 1);
+    if (!fused)                                     // generic / live-PHY kernels: the packing kernel on this step's row
+        return gw_pack_feedback(env, env->st.N, obs_dev, reward_dev, done_dev, feedback_byte_dev, 0, stream);
     return GW_OK;
 }
 

@@ -220,7 +220,7 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
 int gw_launch_received(const GwState& st, int32_t* out, void* stream);
 int gw_launch_enqueue(const GwState& st, int sender, const int32_t* payload_bytes, void* stream);
 int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
-                       int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits);
+                       int32_t* obs, float* reward, uint8_t* done, uint8_t* feedback_byte, void* stream, bool below_limits);
 int gw_launch_reset_sfx(const GwState& st, const uint8_t* mask, int32_t* obs, void* stream);
 int gw_launch_init_sfx(const GwState& st, void* stream);
 int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const int32_t* device, const int32_t* duration,

@@ -11,8 +11,10 @@
 
 typedef int (*gw_step_fn)(void*, const int32_t*, const int32_t*, int32_t*, float*, uint8_t*, void*);
 typedef int (*gw_pend_fn)(void*, void*, const int32_t*, const int32_t*, int32_t*, float*, double*, void*);
+typedef int (*gw_step_fb_fn)(void*, const int32_t*, const int32_t*, int32_t*, float*, uint8_t*, uint8_t*, void*);
 static gw_step_fn g_step = NULL;
 static gw_pend_fn g_pend = NULL;
+static gw_step_fb_fn g_step_fb = NULL;
 
 static int as_ptr(PyObject* o, void** out)
 {
@@ -22,15 +24,27 @@ static int as_ptr(PyObject* o, void** out)
     return 0;
 }
 
-/* bind(addr_of_gw_step, addr_of_gw_pendulum_step) */
+/* bind(addr_of_gw_step, addr_of_gw_pendulum_step, addr_of_gw_step_fb) */
 static PyObject* py_bind(PyObject* self, PyObject* const* args, Py_ssize_t n)
 {
-    void *a = NULL, *b = NULL;
-    if (n != 2) { PyErr_SetString(PyExc_TypeError, "bind(gw_step, gw_pendulum_step)"); return NULL; }
-    if (as_ptr(args[0], &a) || as_ptr(args[1], &b)) return NULL;
+    void *a = NULL, *b = NULL, *c = NULL;
+    if (n != 3) { PyErr_SetString(PyExc_TypeError, "bind(gw_step, gw_pendulum_step, gw_step_fb)"); return NULL; }
+    if (as_ptr(args[0], &a) || as_ptr(args[1], &b) || as_ptr(args[2], &c)) return NULL;
     g_step = (gw_step_fn)a;
     g_pend = (gw_pend_fn)b;
+    g_step_fb = (gw_step_fb_fn)c;
     Py_RETURN_NONE;
+}
+
+/* step_fb(env, device, duration, obs, reward, done, feedback_byte, stream) -> rc */
+static PyObject* py_step_fb(PyObject* self, PyObject* const* args, Py_ssize_t n)
+{
+    void* p[8];
+    if (n != 8 || !g_step_fb) { PyErr_SetString(PyExc_TypeError, "step_fb(env, device, duration, obs, reward, done, feedback_byte, stream) after bind()"); return NULL; }
+    for (int i = 0; i < 8; ++i)
+        if (as_ptr(args[i], &p[i])) return NULL;
+    const int rc = g_step_fb(p[0], (const int32_t*)p[1], (const int32_t*)p[2], (int32_t*)p[3], (float*)p[4], (uint8_t*)p[5], (uint8_t*)p[6], p[7]);
+    return PyLong_FromLong(rc);
 }
 
 /* step(env, device, duration, obs, reward, done, stream) -> rc; all arguments are addresses as Python ints */
@@ -56,8 +70,9 @@ static PyObject* py_pend(PyObject* self, PyObject* const* args, Py_ssize_t n)
 }
 
 static PyMethodDef methods[] = {
-    {"bind", (PyCFunction)(void (*)(void))py_bind, METH_FASTCALL, "bind(gw_step address, gw_pendulum_step address)"},
+    {"bind", (PyCFunction)(void (*)(void))py_bind, METH_FASTCALL, "bind(gw_step address, gw_pendulum_step address, gw_step_fb address)"},
     {"step", (PyCFunction)(void (*)(void))py_step, METH_FASTCALL, "gw_step with addresses as ints"},
+    {"step_fb", (PyCFunction)(void (*)(void))py_step_fb, METH_FASTCALL, "gw_step_fb with addresses as ints"},
     {"pendulum_step", (PyCFunction)(void (*)(void))py_pend, METH_FASTCALL, "gw_pendulum_step with addresses as ints"},
     {NULL, NULL, 0, NULL}};
 

@@ -158,6 +158,7 @@ class VecCounterTrafficEnv(BaseEnv):
 
         self._h = C.c_void_p()
         self._hv = 0
+        self._fb = None
         self._fast = nat.fast()
         self._cuda_get_device = torch._C._cuda_getDevice
         self._cuda_raw_stream = torch._C._cuda_getCurrentRawStream
@@ -273,7 +274,12 @@ class VecCounterTrafficEnv(BaseEnv):
         idx = self._dev_index
         if self._cuda_get_device() == idx:                     # the one-process-per-GPU case: no context switch
             fast = self._fast                                   # CPython fast-call shim (csrc/gw_pyfast.c) when built
-            if fast is not None:
+            fb = self._fb                                       # feedback_bytes_into(): the step's one-byte feedback row
+            if fb is not None:
+                rc = (fast.step_fb if fast is not None else self._L.gw_step_fb)(
+                    self._hv, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), fb.data_ptr(),
+                    self._cuda_raw_stream(idx))
+            elif fast is not None:
                 rc = fast.step(self._hv, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
                                done.data_ptr(), self._cuda_raw_stream(idx))
             else:
@@ -282,14 +288,24 @@ class VecCounterTrafficEnv(BaseEnv):
         else:
             torch = _torch()
             with torch.cuda.device(self.device):
-                rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
-                                     done.data_ptr(), self._stream())
+                rc = self._L.gw_step_fb(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                                        done.data_ptr(), self._fb.data_ptr() if self._fb is not None else None, self._stream())
         if rc:
             nat.check(rc)
         if self._custom is not None:
             return self._feed_custom(dev, dur)
         self._last = (obs, rew, done)
         return obs, rew, done, self._info()
+
+    def feedback_bytes_into(self, row):
+        """From now on every step() also writes its feedback in the one-byte exchange format of ``pack_feedback`` into
+        ``row`` (uint8[N] on this env's GPU; ``None`` switches it off) -- the row a multi-GPU job gathers
+        (``sharding.ChunkedFeedbackGather``).  In the default mode the step kernel stores the byte itself: no packing launch."""
+        if row is not None:
+            torch = _torch()
+            assert (type(row) is torch.Tensor and row.dtype is torch.uint8 and row.device == self.device and row.dim() == 1
+                    and row.shape[0] == self.num_envs and row.is_contiguous()), "feedback row: contiguous uint8[N] on the env's GPU"
+        self._fb = row
 
     def _feed_custom(self, dev, dur):
         """Drive a user-supplied VecInterpreter from what the RRM sniffed in this step."""

@@ -120,7 +120,9 @@ class ChunkedFeedbackGather:
     runs on the backend's stream).  Nothing about the environments themselves is exchanged.
 
     `pack(obs, reward, done, out)` / `unpack(packed, obs, reward, done)` are the byte codec: on a GPU pass
-    `env.pack_feedback` / `env.unpack_feedback` (the HIP kernels behind the C-ABI).
+    `env.pack_feedback` / `env.unpack_feedback` (the HIP kernels behind the C-ABI) -- or `pack=None` when the
+    step itself writes its byte row (`env.feedback_bytes_into(gather.byte_slot())` before each step: the default
+    step kernel stores the byte along with its outputs, so a chunk costs no packing launch at all).
     """
 
     def __init__(self, num_envs, device, pack, world_size=None, chunk=64, depth=2, dist_module=None):
@@ -140,6 +142,7 @@ class ChunkedFeedbackGather:
         self.k = 0                                   # steps handed out so far
         # the per-step views, made once: slot() is on the host's critical path (one call per 7 us step)
         self._views = [[(self.obs[b][j], self.reward[b][j], self.done[b][j]) for j in range(g)] for b in range(depth)]
+        self._byte_rows = [[self.packed[b][j] for j in range(g)] for b in range(depth)]
 
     def slot(self):
         """(obs, reward, done) views the NEXT step must write into."""
@@ -148,6 +151,11 @@ class ChunkedFeedbackGather:
             self.pending[b].wait()
             self.pending[b] = None
         return self._views[b][j]
+
+    def byte_slot(self):
+        """The uint8[N] row of the packed chunk record that belongs to the NEXT step (for steps that write it themselves)."""
+        b, j = (self.k // self.chunk) % self.depth, self.k % self.chunk
+        return self._byte_rows[b][j]
 
     def stepped(self):
         """Call after each step; starts the chunk's pack + all-gather when the chunk is full.
@@ -159,7 +167,8 @@ class ChunkedFeedbackGather:
         return self._submit(b, self.chunk)
 
     def _submit(self, b, steps):
-        self._pack(self.obs[b][:steps], self.reward[b][:steps], self.done[b][:steps], self.packed[b][:steps])
+        if self._pack is not None:                   # (None: every step of the chunk wrote its own row, see byte_slot)
+            self._pack(self.obs[b][:steps], self.reward[b][:steps], self.done[b][:steps], self.packed[b][:steps])
         self.filled[b] = steps
         # only the rows that were filled travel: a partial chunk (the flush at the end of a short run) costs steps/chunk of a
         # full one on the links, not all of it

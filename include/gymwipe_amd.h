@@ -35,6 +35,7 @@
  *   gw_delivered       what SimpleRrmDevice.onPacketReceived feeds a custom Interpreter     networking/devices.py:163-168
  *   gw_enqueue         SimpleNetworkDevice.send -> SimpleMac queue           networking/devices.py:84-86, simple_stack.py:463-471
  *   gw_rollout         a Python loop over step()
+ *   gw_step_fb         gw_step + the step's feedback as one byte per env (the row a multi-GPU job gathers)
  *   gw_pack_feedback / gw_unpack_feedback   (multi-GPU exchange format; the reference is single-process)
  *   gw_pendulum_step   InvertedPendulumEnv.step              envs/inverted_pendulum.py:101-113
  *   gw_plant_*         OdePlant.updateState, SlidingPendulum getters / setMotorVelocity   plants/core.py:38-49,
@@ -159,6 +160,13 @@ int gw_reset(gw_env* env, const uint8_t* mask_dev, int32_t* obs_dev, void* strea
 /* one env.step() for all N envs.  device_dev in [0,D), duration_dev in [0,max_duration). */
 int gw_step(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
             int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, void* stream);
+
+/* gw_step that ALSO writes the step's feedback in the one-byte exchange format of gw_pack_feedback (below) to
+ * feedback_byte_dev[N] -- the row a multi-GPU job all-gathers at the end of the step (Interpreter.getFeedback, envs/core.py:142-153,
+ * in the form the gather moves).  Fused into the step kernel in the default mode (one more byte stored per env, no extra launch);
+ * the other modes run gw_step and then the packing kernel.  feedback_byte_dev == NULL: exactly gw_step. */
+int gw_step_fb(gw_env* env, const int32_t* device_dev, const int32_t* duration_dev,
+               int32_t* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* feedback_byte_dev, void* stream);
 
 /* SimpleNetworkDevice.send(data, dest[sender]) (networking/devices.py:84-86) -> SimpleMac queue append with
  * drop-oldest (simple_stack.py:463-471), for every env with payload_bytes_dev[e] >= 0 (int32[N]: byte size of

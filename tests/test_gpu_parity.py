@@ -346,6 +346,37 @@ def test_feedback_byte_codec_kernels():
         env.pack_feedback(obs, rew, done, check=True)
 
 
+@pytest.mark.parametrize("D,kw", [(4, {}), (16, {}), (5, {}), (4, {"explicit": True}), (4, {"per_env_geometry": True})])
+def test_step_writes_its_feedback_byte_row(D, kw):
+    """gw_step_fb (env.feedback_bytes_into): the step kernel stores the one-byte exchange form of its own feedback -- equal to
+    what the packing kernel makes of (obs, reward, done), invalid actions included; the generic and live-PHY modes get there
+    through the packing kernel.  With the row switched off the step is plain gw_step again."""
+    import torch
+    N, K = 1000, 40
+    kw = dict(kw)
+    explicit = kw.pop("explicit", False)
+    env, _ = _mk(N, D, explicit=explicit, **kw)            # (parity of the outputs themselves is the other tests' business)
+    dev, dur = action_stream(33, K, N, D)
+    dev[3, 5] = D + 2                                          # invalid actions keep their env's previous feedback, reward 0
+    dur[9, 7] = 99
+    rows = torch.zeros((K, N), dtype=torch.uint8, device="cuda")
+    env.reset()
+    seen = set()
+    for k in range(K):
+        if k % 16 == 0 and k:
+            env.reset()
+        env.feedback_bytes_into(rows[k] if k != 20 else None)
+        o, r, d, _ = env.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+        if k != 20:
+            assert torch.equal(rows[k], env.pack_feedback(o, r, d, check=True)), k
+            seen.update(rows[k].unique().tolist())
+    assert len(seen) >= 4, seen                                # the run produced several different feedback values
+    assert env.stats()["bad_actions"] == 2
+    assert not rows[20].any()                                  # switched off: nothing written
+    with pytest.raises(AssertionError):
+        env.feedback_bytes_into(torch.zeros(N + 1, dtype=torch.uint8, device="cuda"))
+
+
 # ---- BASELINE.json's full sizes ------------------------------------------------------------------------
 @pytest.mark.parametrize("D,K", [(4, 192), (16, 64)])
 def test_parity_at_full_baseline_size(D, K):

@@ -123,7 +123,26 @@ def cpu_baseline(D, W, K, seconds_target=10.0, single_thread_seconds=2.5, other_
     return out
 
 
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """The ONE line this program prints: written to the stdout the process was started with.  Everything else that lands on
+    fd 1 (RCCL prints a five-line version banner there when its communicator is created) is sent to stderr instead."""
+    data = (line + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)      # SURVEY 8d: 64 warm-up + 1 024 timed steps
@@ -148,7 +167,7 @@ def main():
         args.devices = 16
     if args.config == 4:
         import bench_pendulum                                    # tools-level module next to this file
-        return bench_pendulum.main(args)
+        return bench_pendulum.main(args, emit)
     if args.envs is None:
         args.envs = 65536
 
@@ -486,7 +505,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:           # reported at N = 1 only (the other ranks would idle)
             cs = args.cpu_seconds
             out["cpu_baseline"] = cpu_baseline(D, W, K, cs, min(2.5, cs / 4), other_seconds=min(2.0, cs / 5))
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -79,7 +79,7 @@ def cpu_baseline(N_gpu, W, K, seconds):
                       "plant recurrence (oracle/plant_oracle.c, one thread), %.1f s" % (n_env - 1, W + K, cores, el)}
 
 
-def main(args):
+def main(args, emit=print):
     import torch
     from gymwipe_amd import VecInvertedPendulumEnv
     from gymwipe_amd.actions import actions_torch
@@ -171,7 +171,7 @@ def main(args):
            "roofline": roof}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(N, W, K, max(2.0, args.cpu_seconds))
-    print(json.dumps(out))
+    emit(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -236,16 +236,20 @@ def main():
     a_dev, a_dur = actions_torch(SEED, rank * N, (rank + 1) * N, 0, W + K, D, device=dev_t)
     acts = [{"device": a_dev[i], "duration": a_dur[i]} for i in range(W + K)]
 
+    fused_rows = pipe is not None and pipe._pack is None
+    views = [pipe.begin() if pipe is not None else None]
+
     def one(i):
-        if pipe is not None:                      # this step's outputs go into the current chunk record
-            env._obs, env._rew, env._done = pipe.slot()
-            if pipe._pack is None:
-                env._fb = pipe.byte_slot()
+        if pipe is not None:                      # this step's outputs go into the current chunk record; in the RCCL path the
+            v = views[0]                          # step kernel writes its one-byte feedback row there as well (gw_step_fb)
+            env._obs, env._rew, env._done = v[0], v[1], v[2]
+            if fused_rows:
+                env._fb = v[3]
         if i % RESET_EVERY == 0:
             env.reset()                           # (its observation lands in the slot the step then overwrites)
         env.step(acts[i])
         if pipe is not None:
-            pipe.stepped()                        # every 64th step: pack to bytes + async all-gather over RCCL
+            views[0] = pipe.advance()             # chunk full: async all-gather over RCCL (+ the packing kernel in the rehearsal)
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
@@ -255,6 +259,7 @@ def main():
             one(i)
         if pipe is not None:
             pipe.drain()                              # the warm-up steps' feedback leaves before the clock starts
+            views[0] = pipe.begin()
         s0 = env.stats() if with_stats else None   # (synchronises)
         if multi:
             dist.barrier()
@@ -266,6 +271,7 @@ def main():
         ev[1].record()
         if pipe is not None:
             pipe.drain()                              # the job is done when the last gather has landed
+            views[0] = pipe.begin()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         if multi:

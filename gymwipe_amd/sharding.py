@@ -143,6 +143,7 @@ class ChunkedFeedbackGather:
         # the per-step views, made once: slot() is on the host's critical path (one call per 7 us step)
         self._views = [[(self.obs[b][j], self.reward[b][j], self.done[b][j]) for j in range(g)] for b in range(depth)]
         self._byte_rows = [[self.packed[b][j] for j in range(g)] for b in range(depth)]
+        self._slots = [self._views[b][j] + (self._byte_rows[b][j],) for b in range(depth) for j in range(g)]
 
     def slot(self):
         """(obs, reward, done) views the NEXT step must write into."""
@@ -151,6 +152,27 @@ class ChunkedFeedbackGather:
             self.pending[b].wait()
             self.pending[b] = None
         return self._views[b][j]
+
+    # -- the same protocol with ONE call per step (the host has ~1 us to spare per 6-us step) --------------------------
+    #    views = g.begin()            # (obs, reward, done, byte_row) of the next step; again after every drain()
+    #    loop:  step into `views`;  views = g.advance()
+    def begin(self):
+        """(obs, reward, done, byte_row) views the next step must write into."""
+        b, j = (self.k // self.chunk) % self.depth, self.k % self.chunk
+        if j == 0 and self.pending[b] is not None:   # this buffer's previous gather must have landed
+            self.pending[b].wait()
+            self.pending[b] = None
+        return self._slots[b * self.chunk + j]
+
+    def advance(self):
+        """After a step: submits the chunk if that step filled it, and returns the views of the step after it."""
+        k = self.k
+        self.k = k + 1
+        j = k % self.chunk
+        if j + 1 == self.chunk:
+            self._submit((k // self.chunk) % self.depth, self.chunk)
+            return self.begin()
+        return self._slots[((k // self.chunk) % self.depth) * self.chunk + j + 1]
 
     def byte_slot(self):
         """The uint8[N] row of the packed chunk record that belongs to the NEXT step (for steps that write it themselves)."""

@@ -78,8 +78,9 @@ def test_eight_shards_equal_one_handle_with_both_gathers():
 
     chunk = 16                                               # 4 chunks in 64 steps: the double buffers rotate twice
     lb_c, lb_s = LoopbackWorld(WORLD), LoopbackWorld(WORLD)
-    pipes = [ChunkedFeedbackGather(SHARD, "cuda", shards[r].pack_feedback, WORLD, chunk=chunk, dist_module=lb_c.rank(r))
-             for r in range(WORLD)]
+    # pack=None + begin()/advance(): bench.py's production protocol -- every step writes its own one-byte row (gw_step_fb)
+    pipes = [ChunkedFeedbackGather(SHARD, "cuda", None, WORLD, chunk=chunk, dist_module=lb_c.rank(r)) for r in range(WORLD)]
+    views = [p.begin() for p in pipes]
     recs = [StepRecord(SHARD, "cuda") for _ in range(WORLD)]
     gathers = [ObservationGather(recs[r], WORLD, dist_module=lb_s.rank(r)) for r in range(WORLD)]
 
@@ -97,10 +98,13 @@ def test_eight_shards_equal_one_handle_with_both_gathers():
             lo, hi = lo_hi[r]
             act = {"device": a_dev[k, lo:hi], "duration": a_dur[k, lo:hi]}
             if k < K // 2:                                   # first half: the chunked byte gather
-                s._obs, s._rew, s._done = pipes[r].slot()
+                v = views[r]
+                s._obs, s._rew, s._done = v[0], v[1], v[2]
+                s.feedback_bytes_into(v[3])
                 s.step(act)
-                pipes[r].stepped()
+                views[r] = pipes[r].advance()
             else:                                            # second half: the literal per-step record gather
+                s.feedback_bytes_into(None)
                 s._obs, s._rew, s._done = recs[r].obs, recs[r].reward, recs[r].done
                 s.step(act)
                 gathers[r]()

@@ -260,3 +260,46 @@ def test_fastcall_shim_reaches_the_same_entry_points():
         f.step(0, 1, 1)
     with pytest.raises((TypeError, OverflowError)):
         f.step(0, 1, 1, 1, 1, "x", 0)
+
+
+def test_chunked_gather_one_call_protocol_matches_the_two_call_one():
+    """ChunkedFeedbackGather.begin()/advance() (one call per step, what bench.py uses) submits the same chunks, in the same
+    order and with the same contents, as slot()/stepped(), including a drain in the middle and a ragged tail."""
+    import torch
+    from gymwipe_amd.sharding import ChunkedFeedbackGather
+
+    class Work:
+        def wait(self):
+            pass
+
+    class Dist:
+        def __init__(self):
+            self.calls = []
+
+        def all_gather_into_tensor(self, out, inp, async_op=True):
+            out[:inp.numel()] = inp
+            self.calls.append(inp.clone())
+            return Work()
+
+    def pack(o, r, d, out):
+        out.copy_((o % 251).to(torch.uint8))
+
+    for K in (7, 16, 37):
+        a, b = Dist(), Dist()
+        two = ChunkedFeedbackGather(5, "cpu", pack, 1, chunk=4, dist_module=a)
+        one = ChunkedFeedbackGather(5, "cpu", pack, 1, chunk=4, dist_module=b)
+        v = one.begin()
+        for k in range(K):
+            o, r, d = two.slot()
+            o.fill_(k)
+            two.stepped()
+            assert len(v) == 4 and v[3].dtype == torch.uint8 and v[3].shape == (5,)
+            v[0].fill_(k)
+            v = one.advance()
+            if k == 9:
+                two.drain()
+                one.drain()
+                v = one.begin()
+        two.drain()
+        one.drain()
+        assert len(a.calls) == len(b.calls) and all(torch.equal(x, y) for x, y in zip(a.calls, b.calls)), K

@@ -232,12 +232,13 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     csrc = os.path.join(ROOT, "gymwipe_amd", "csrc")
+    # the product build's own flags (scheduling strategy, kernarg preload, ...: they change register allocation)
+    flags = subprocess.run(["make", "-s", "-C", csrc, "print-flags"], check=True, capture_output=True, text=True).stdout.split()
+    assert "--offload-arch=gfx950" in flags and "-ffp-contract=off" in flags, flags
     for src in ("ct_step_sfx.hip", "ct_rollout_sfx.hip", "ct_step.hip", "ct_step_dyn.hip"):
         out = tmp_path / (src + ".s")
-        subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
-                        "--offload-arch=gfx950",
-                        "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", "-o", str(out), "-x", "hip",
-                        os.path.join(csrc, src)], check=True, capture_output=True, timeout=900)
+        subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out), "-x", "hip", os.path.join(csrc, src)],
+                       check=True, capture_output=True, timeout=900, cwd=csrc)
         text = out.read_text()
         sizes = re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)
         names = re.findall(r"^\s+\.name:\s+(\S+)", text, re.M)

@@ -123,7 +123,9 @@ def build(force=False, quiet=True):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
             if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(_PKG, "..", "include", "gymwipe_amd.h")]
     shim = os.path.join(os.path.dirname(LIB_PATH), "_gw_fast.so")            # CPython fast-call shim, same Makefile
-    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(shim)
+    xoff = os.path.join(os.path.dirname(LIB_PATH), "libgymwipe_amd_xnackoff.so")
+    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(shim) or not os.path.exists(xoff)
+             or os.path.getmtime(xoff) < os.path.getmtime(LIB_PATH)
              or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
              or os.path.getmtime(os.path.join(CSRC, "gw_pyfast.c")) > os.path.getmtime(shim))
     if force or stale:
@@ -133,6 +135,25 @@ def build(force=False, quiet=True):
 
 
 _lib = None
+
+
+def _pick_library():
+    """The library to load: $GW_LIB if given; else the build for XNACK-off devices (libgymwipe_amd_xnackoff.so, 3.5 % faster
+    step kernels) when the GPU says it runs with XNACK off -- a code object compiled for xnack- would not load otherwise --;
+    else the build for any XNACK setting.  Same sources, same C-ABI, same results."""
+    if os.environ.get("GW_LIB"):
+        return LIB_PATH
+    xoff = os.path.join(os.path.dirname(LIB_PATH), "libgymwipe_amd_xnackoff.so")
+    if os.path.exists(xoff) and not os.environ.get("GW_NO_XNACKOFF"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                names = {torch.cuda.get_device_properties(i).gcnArchName for i in range(torch.cuda.device_count())}
+                if names and all("xnack-" in n for n in names):
+                    return xoff
+        except Exception:
+            pass
+    return LIB_PATH
 
 
 def lib():
@@ -154,7 +175,7 @@ def lib():
         import torch  # noqa: F401  -- load torch's HIP runtime first so both share one libamdhip64
     except Exception:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(_pick_library())
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.gw_abi_version.argtypes, L.gw_abi_version.restype = [], C.c_int
     L.gw_last_error.argtypes, L.gw_last_error.restype = [], C.c_char_p

@@ -735,3 +735,14 @@ def test_ordering_edge_cases_on_the_gpu(case, explicit):
         for k in range(len(acts)):
             assert (fo[k].cpu().numpy() == outs[k][0]).all() and (fr[k].cpu().numpy() == outs[k][1]).all(), k
         assert_state_equal(fused, orc, STATE_FIELDS, where=case + " (rollout)")
+
+
+def test_loader_picks_the_build_that_matches_the_devices_xnack_mode():
+    import torch
+    from gymwipe_amd import _native as nat
+    arch = torch.cuda.get_device_properties(0).gcnArchName
+    picked = os.path.basename(nat._pick_library())
+    if os.environ.get("GW_LIB"):
+        pytest.skip("GW_LIB set")
+    assert picked == ("libgymwipe_amd_xnackoff.so" if "xnack-" in arch else "libgymwipe_amd.so"), (arch, picked)
+    assert nat.lib()._name.endswith(picked)

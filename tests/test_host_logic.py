@@ -304,3 +304,22 @@ def test_chunked_gather_one_call_protocol_matches_the_two_call_one():
         two.drain()
         one.drain()
         assert len(a.calls) == len(b.calls) and all(torch.equal(x, y) for x, y in zip(a.calls, b.calls)), K
+
+
+def test_both_library_builds_export_the_c_abi_and_the_loader_defaults_to_the_portable_one():
+    """libgymwipe_amd.so (any XNACK setting) and libgymwipe_amd_xnackoff.so (xnack- code objects, picked by the loader only when
+    the device reports xnack-) are the same sources: both export every declared symbol.  Without a GPU the loader takes the
+    portable build."""
+    import ctypes
+    from gymwipe_amd import _native as nat
+    lib_dir = os.path.dirname(nat.LIB_PATH)
+    for name in ("libgymwipe_amd.so", "libgymwipe_amd_xnackoff.so"):
+        path = os.path.join(lib_dir, name)
+        assert os.path.exists(path), "%s missing: make -C gymwipe_amd/csrc" % path
+        L = ctypes.CDLL(path)
+        for sym in nat.EXPORTS:
+            getattr(L, sym)
+        assert L.gw_abi_version() == nat.ABI_VERSION
+    import torch
+    if not torch.cuda.is_available() and not os.environ.get("GW_LIB"):
+        assert nat._pick_library() == nat.LIB_PATH

@@ -235,9 +235,11 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
     # the product build's own flags (scheduling strategy, kernarg preload, ...: they change register allocation)
     flags = subprocess.run(["make", "-s", "-C", csrc, "print-flags"], check=True, capture_output=True, text=True).stdout.split()
     assert "--offload-arch=gfx950" in flags and "-ffp-contract=off" in flags, flags
-    for src in ("ct_step_sfx.hip", "ct_rollout_sfx.hip", "ct_step.hip", "ct_step_dyn.hip"):
+    xoff = [f + ":xnack-" if f == "--offload-arch=gfx950" else f for f in flags]       # the second library's target
+    for src, fl in (("ct_step_sfx.hip", flags), ("ct_rollout_sfx.hip", flags), ("ct_step.hip", flags), ("ct_step_dyn.hip", flags),
+                    ("ct_step_sfx.hip", xoff), ("ct_rollout_sfx.hip", xoff)):
         out = tmp_path / (src + ".s")
-        subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out), "-x", "hip", os.path.join(csrc, src)],
+        subprocess.run([hipcc] + fl + ["-S", "--cuda-device-only", "-o", str(out), "-x", "hip", os.path.join(csrc, src)],
                        check=True, capture_output=True, timeout=900, cwd=csrc)
         text = out.read_text()
         sizes = re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", text, re.M)

@@ -23,6 +23,8 @@ run occ_524288                    $B --envs 524288 --steps 256 --no-cpu-baseline
 run generic_kernel                python3 tools/bench_generic.py
 run live_phy                      python3 tools/bench_live_phy.py
 run control_loop                  python3 tools/bench_control.py
+run grid_phy                      python3 tools/bench_grid.py
+run plant_mfma                    python3 tools/bench_plant.py
 run host_overhead                 python3 tools/host_overhead.py
 python3 - <<PY
 import json, glob, os

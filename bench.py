@@ -239,17 +239,22 @@ def main():
     fused_rows = pipe is not None and pipe._pack is None
     views = [pipe.begin() if pipe is not None else None]
 
+    from gymwipe_amd import StepOutputs
+    own = StepOutputs(rec.obs, rec.reward, rec.done)     # N = 1: every step writes the same record
+
     def one(i):
-        if pipe is not None:                      # this step's outputs go into the current chunk record; in the RCCL path the
-            v = views[0]                          # step kernel writes its one-byte feedback row there as well (gw_step_fb)
-            env._obs, env._rew, env._done = v[0], v[1], v[2]
-            if fused_rows:
-                env._fb = v[3]
         if i % RESET_EVERY == 0:
-            env.reset()                           # (its observation lands in the slot the step then overwrites)
-        env.step(acts[i])
-        if pipe is not None:
-            views[0] = pipe.advance()             # chunk full: async all-gather over RCCL (+ the packing kernel in the rehearsal)
+            env.reset()
+        if pipe is None:
+            env.step(acts[i], own)
+        elif fused_rows:                          # this step's outputs go into the current chunk record, its one-byte feedback
+            env.step(acts[i], views[0])           # row included (gw_step_fb): views[0] is the chunk slot's StepOutputs
+            views[0] = pipe.advance()             # chunk full: async all-gather over RCCL
+        else:                                     # rehearsal: typed outputs into the chunk record, packing kernel per chunk
+            v = views[0]
+            env._obs, env._rew, env._done = v[0], v[1], v[2]
+            env.step(acts[i])
+            views[0] = pipe.advance()
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
@@ -387,11 +392,11 @@ def main():
         env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
         n_ss = max(64, min(256, W + K))
         for j in range(64):
-            env.step(acts[j % (W + K)])
+            env.step(acts[j % (W + K)], own)
 
         def run():
             for j in range(n_ss):
-                env.step(acts[j % (W + K)])
+                env.step(acts[j % (W + K)], own)
         ss_wall = best_of(run, 3)
         return {"env_steps_per_s_this_rank": N * n_ss / ss_wall, "ms_per_step": ss_wall / n_ss * 1e3, "steps": n_ss,
                 "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "

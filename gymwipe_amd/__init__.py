@@ -12,7 +12,7 @@ fallback: without the HIP library or a GPU the envs raise.
 from . import spaces                                   # noqa: F401
 from .plants import VecLinearPlant                       # noqa: F401
 from .grid import VecPhyGrid                            # noqa: F401
-from .envs import (CounterTrafficEnv, VecCounterTrafficEnv, InvertedPendulumEnv, VecInvertedPendulumEnv, VecControlLoopEnv,   # noqa: F401
+from .envs import (CounterTrafficEnv, StepOutputs, VecCounterTrafficEnv, InvertedPendulumEnv, VecInvertedPendulumEnv, VecControlLoopEnv,   # noqa: F401
                    Interpreter,
                    VecInterpreter, VecPayload,
                    make, register, registry)

@@ -4,7 +4,7 @@ Environment registry with the reference's ids (gymwipe/envs/__init__.py:6-14).
 ``gym`` package is importable the ids are registered there too.
 """
 from .core import BaseEnv, Interpreter, VecInterpreter, VecPayload       # noqa: F401
-from .counter_traffic import CounterTrafficEnv, VecCounterTrafficEnv     # noqa: F401
+from .counter_traffic import CounterTrafficEnv, StepOutputs, VecCounterTrafficEnv     # noqa: F401
 from .inverted_pendulum import InvertedPendulumEnv, VecControlLoopEnv, VecInvertedPendulumEnv   # noqa: F401
 
 registry = {}

@@ -59,6 +59,28 @@ class _DeviceInterpreter(Interpreter):
         return self._env._info()
 
 
+class StepOutputs:
+    """Where one ``env.step(action, out=...)`` writes: ``obs`` int32[N], ``reward`` float32[N], ``done`` uint8[N] and, optionally,
+    ``feedback_bytes`` uint8[N] (the step's feedback in the one-byte exchange format, ``gw_step_fb``) -- preallocated,
+    contiguous tensors on the env's GPU.  Their device addresses are taken ONCE, here (a step is enqueued every few
+    microseconds; four ``data_ptr()`` calls are 10 % of that), so the tensors must not be resized or re-pointed afterwards;
+    the object keeps them alive."""
+    __slots__ = ("obs", "reward", "done", "feedback_bytes", "_ptrs", "_as_tuple")
+
+    def __init__(self, obs, reward, done, feedback_bytes=None):
+        torch = _torch()
+        n = obs.shape[0]
+        for t, dt in ((obs, torch.int32), (reward, torch.float32), (done, torch.uint8), (feedback_bytes, torch.uint8)):
+            if t is None:
+                continue
+            assert (type(t) is torch.Tensor and t.dtype is dt and t.dim() == 1 and t.shape[0] == n and t.is_contiguous()
+                    and t.device == obs.device and t.is_cuda), "StepOutputs: contiguous 1-D tensors of one length on one GPU"
+        self.obs, self.reward, self.done, self.feedback_bytes = obs, reward, done, feedback_bytes
+        self._ptrs = (obs.data_ptr(), reward.data_ptr(), done.data_ptr(),
+                      feedback_bytes.data_ptr() if feedback_bytes is not None else 0)
+        self._as_tuple = (obs, reward, done)
+
+
 class VecCounterTrafficEnv(BaseEnv):
     """N CounterTraffic environments on one MI355X.
 
@@ -251,11 +273,12 @@ class VecCounterTrafficEnv(BaseEnv):
         self._seen[id(t)] = weakref.ref(t)                   # weak: the env must not keep a caller's action buffers alive
         return t
 
-    def step(self, action):
+    def step(self, action, out=None):
         """One env.step() for all N envs: ``action = {"device": int32[N], "duration": int32[N]}``
         (torch tensors on the env's GPU are used in place).  Returns
         ``(obs int32[N], reward float32[N], done uint8[N], info)``; an action outside the action
-        space flags its env (``check()`` raises) and leaves that env untouched."""
+        space flags its env (``check()`` raises) and leaves that env untouched.
+        ``out``: a ``StepOutputs`` to write this step's outputs into (instead of the env's own buffers)."""
         # (this method is enqueued ~200 000 times a second: the common path -- pre-staged int32 tensors on this GPU, reused
         #  output buffers, the caller on this env's device -- is written out flat, without helper calls)
         dev = action["device"]
@@ -267,14 +290,27 @@ class VecCounterTrafficEnv(BaseEnv):
         hit = seen.get(id(dur))
         if hit is None or hit() is not dur:
             dur = self._checked(dur, "duration")
-        if self._reuse:
-            obs, rew, done = self._obs, self._rew, self._done
-        else:
-            obs, rew, done = self._outputs()
         idx = self._dev_index
+        if out is not None and self._cuda_get_device() == idx and self._fast is not None and self._custom is None:
+            p = out._ptrs                                       # preallocated outputs, addresses taken at construction
+            if p[3]:
+                rc = self._fast.step_fb(self._hv, dev.data_ptr(), dur.data_ptr(), p[0], p[1], p[2], p[3], self._cuda_raw_stream(idx))
+            else:
+                rc = self._fast.step(self._hv, dev.data_ptr(), dur.data_ptr(), p[0], p[1], p[2], self._cuda_raw_stream(idx))
+            if rc:
+                nat.check(rc)
+            self._last = out._as_tuple
+            return out.obs, out.reward, out.done, self._info()
+        if out is not None:                                     # (no shim / another device current / custom interpreter: the general path)
+            obs, rew, done, fb = out.obs, out.reward, out.done, out.feedback_bytes
+        else:
+            fb = self._fb                                       # feedback_bytes_into(): the step's one-byte feedback row
+            if self._reuse:
+                obs, rew, done = self._obs, self._rew, self._done
+            else:
+                obs, rew, done = self._outputs()
         if self._cuda_get_device() == idx:                     # the one-process-per-GPU case: no context switch
             fast = self._fast                                   # CPython fast-call shim (csrc/gw_pyfast.c) when built
-            fb = self._fb                                       # feedback_bytes_into(): the step's one-byte feedback row
             if fb is not None:
                 rc = (fast.step_fb if fast is not None else self._L.gw_step_fb)(
                     self._hv, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), fb.data_ptr(),
@@ -289,7 +325,7 @@ class VecCounterTrafficEnv(BaseEnv):
             torch = _torch()
             with torch.cuda.device(self.device):
                 rc = self._L.gw_step_fb(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
-                                        done.data_ptr(), self._fb.data_ptr() if self._fb is not None else None, self._stream())
+                                        done.data_ptr(), fb.data_ptr() if fb is not None else None, self._stream())
         if rc:
             nat.check(rc)
         if self._custom is not None:

@@ -144,6 +144,9 @@ class ChunkedFeedbackGather:
         self._views = [[(self.obs[b][j], self.reward[b][j], self.done[b][j]) for j in range(g)] for b in range(depth)]
         self._byte_rows = [[self.packed[b][j] for j in range(g)] for b in range(depth)]
         self._slots = [self._views[b][j] + (self._byte_rows[b][j],) for b in range(depth) for j in range(g)]
+        if pack is None and self.obs[0].is_cuda:     # steps write their own byte rows: hand out ready-made StepOutputs
+            from .envs.counter_traffic import StepOutputs
+            self._slots = [StepOutputs(*v) for v in self._slots]
 
     def slot(self):
         """(obs, reward, done) views the NEXT step must write into."""
@@ -156,6 +159,7 @@ class ChunkedFeedbackGather:
     # -- the same protocol with ONE call per step (the host has ~1 us to spare per 6-us step) --------------------------
     #    views = g.begin()            # (obs, reward, done, byte_row) of the next step; again after every drain()
     #    loop:  step into `views`;  views = g.advance()
+    #    With pack=None on a GPU the views are `StepOutputs` objects: `env.step(action, out=views)`.
     def begin(self):
         """(obs, reward, done, byte_row) views the next step must write into."""
         b, j = (self.k // self.chunk) % self.depth, self.k % self.chunk

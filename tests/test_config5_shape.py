@@ -98,10 +98,7 @@ def test_eight_shards_equal_one_handle_with_both_gathers():
             lo, hi = lo_hi[r]
             act = {"device": a_dev[k, lo:hi], "duration": a_dur[k, lo:hi]}
             if k < K // 2:                                   # first half: the chunked byte gather
-                v = views[r]
-                s._obs, s._rew, s._done = v[0], v[1], v[2]
-                s.feedback_bytes_into(v[3])
-                s.step(act)
+                s.step(act, out=views[r])                    # a StepOutputs: typed outputs + the step's one-byte row
                 views[r] = pipes[r].advance()
             else:                                            # second half: the literal per-step record gather
                 s.feedback_bytes_into(None)

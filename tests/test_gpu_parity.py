@@ -373,6 +373,21 @@ def test_step_writes_its_feedback_byte_row(D, kw):
     assert len(seen) >= 4, seen                                # the run produced several different feedback values
     assert env.stats()["bad_actions"] == 2
     assert not rows[20].any()                                  # switched off: nothing written
+    # the same through preallocated outputs (env.step(action, out=StepOutputs)): typed outputs and byte row land in the slot
+    from gymwipe_amd import StepOutputs
+    slot = StepOutputs(torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.float32, device="cuda"),
+                       torch.zeros(N, dtype=torch.uint8, device="cuda"), torch.zeros(N, dtype=torch.uint8, device="cuda"))
+    plain = StepOutputs(torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.float32, device="cuda"),
+                        torch.zeros(N, dtype=torch.uint8, device="cuda"))
+    env.feedback_bytes_into(None)
+    act = {"device": torch.from_numpy(dev[1]), "duration": torch.from_numpy(dur[1])}
+    o, r, d, _ = env.step(act, out=slot)
+    assert o is slot.obs and r is slot.reward and d is slot.done and o.any()
+    assert torch.equal(slot.feedback_bytes, env.pack_feedback(o, r, d, check=True))
+    o2, r2, d2, _ = env.step(act, out=plain)
+    assert o2 is plain.obs and torch.equal(env.received()[:, 0] != 0, env.received()[:, 0] != 0)
+    o3, r3, d3, _ = env.step(act)                              # and the env's own buffers again afterwards
+    assert o3 is not plain.obs and o3 is not slot.obs
     with pytest.raises(AssertionError):
         env.feedback_bytes_into(torch.zeros(N + 1, dtype=torch.uint8, device="cuda"))
 

@@ -34,6 +34,20 @@ for N in (64, 65536):
         best_enq = min(best_enq, (t1 - t0) / 20)
         best_tot = min(best_tot, (t2 - t0) / 20)
     out["N=%d" % N] = {"enqueue_us_per_step": best_enq * 1e6, "wall_us_per_step_incl_sync": best_tot * 1e6}
+    # (a') the same with preallocated outputs, env.step(action, out=StepOutputs): no data_ptr() calls for the outputs
+    slot = gymwipe_amd.StepOutputs(torch.empty(N, dtype=torch.int32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda"),
+                                   torch.empty(N, dtype=torch.uint8, device="cuda"))
+    best_out = 1e9
+    for rep in range(20):
+        env.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(20):
+            env.step(acts[i + 5], slot)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        best_out = min(best_out, (t1 - t0) / 20)
+    out["N=%d" % N]["enqueue_us_per_step_with_out"] = best_out * 1e6
     # (b) one launch + synchronize
     lat = []
     for rep in range(50):

@@ -24,6 +24,13 @@ for _ in range(32):
     obs, reward, done, info = venv.step(action)
 print("vectorised:", obs[:4].tolist(), reward[:4].tolist(), venv.stats())
 
+# 2b. preallocated outputs (their device addresses are taken once): what a tight loop, or a multi-GPU gather record, steps into
+slot = gymwipe_amd.StepOutputs(torch.empty(N, dtype=torch.int32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda"),
+                               torch.empty(N, dtype=torch.uint8, device="cuda"),
+                               feedback_bytes=torch.empty(N, dtype=torch.uint8, device="cuda"))   # + the one-byte exchange format
+obs, reward, done, info = venv.step(action, out=slot)
+print("step(out=):", obs is slot.obs, slot.feedback_bytes[:4].tolist())
+
 # 3. pre-staged actions: 64 steps in one persistent launch
 dev = torch.randint(0, 4, (64, N), dtype=torch.int32, device="cuda")
 dur = torch.randint(0, 20, (64, N), dtype=torch.int32, device="cuda")

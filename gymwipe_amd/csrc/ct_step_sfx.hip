@@ -67,16 +67,17 @@ __device__ __forceinline__ uint32_t word_of(const uint4& w, int i)          // i
 }
 
 
-// Step tables ("blob", built by the host at gw_create: gw_api.cpp; byte offsets all multiples of 16).
-// Staged in LDS, because the step's first decisions wait on two dependent lookups in them:
-//   ber  f64[2][D][S]  [0][d][s]: sender d hearing the RRM in NEW state s;  [1][d][s]: the RRM hearing sender d
-//   mi   u32[D][2]     {mult, ceil(65536/mult)} per sender
-//   h1   u8[D][S]      state of sender j after the announcement:            trans[j][RRM][s0]
-//   r1   u8[D][S]      state of the RRM after one packet of sender d:       trans[RRM][d][s0]
-//   cls  u8[2][D][S]   decode certainty, same indexing as ber
+// Step tables (GwStripeLayout, gw_internal.h; built by the host at gw_create: gw_api.cpp; state-major, so that only the
+// stripes of the noise states this handle's layout has are staged).  In LDS, because the step's first decisions wait on two
+// dependent lookups in them:
+//   mi    u32[D][2]   {mult, ceil(65536/mult)} per sender
+//   per state s:  ber0 f64[D]  sender d hearing the RRM in NEW state s      ber1 f64[D]  the RRM hearing sender d
+//                 h1 u8[D]     state of sender j after the announcement (trans[j][RRM][s])
+//                 r1 u8[D]     state of the RRM after one packet of sender d (trans[RRM][d][s])
+//                 cls0 / cls1 u8[D]  decode certainty, same indexing as ber0 / ber1
 // Read straight from HBM/L2 (issued before the window loop, consumed after it, so the latency is hidden):
-//   h2   u8[D][D][S]   state of sender j after the announcement AND >= 1 data packet of d (valid when hearing the
-//                      same talker twice changes nothing more, which gw_create verifies: idem_states)
+//   h2    u8[S][D][D] state of sender j after the announcement AND >= 1 data packet of d (valid when hearing the
+//                     same talker twice changes nothing more, which gw_create verifies: idem_states)
 
 // Keep a wave-uniform constant in registers from here on: without this the compiler re-loads kernel
 // arguments (s_load + s_waitcnt) at a dozen points of the step, each exposing the scalar-cache latency;
@@ -100,6 +101,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                                                  float* __restrict__ reward,
                                                  uint8_t* __restrict__ done,
                                                  uint8_t* __restrict__ fb,          // one-byte feedback row (gw_step_fb) or null
+                                                 int n_stage,                       // 16-byte chunks of the tables to stage
                                                  double& now_out, bool& live_out)
 {
     constexpr bool PACKED = DT > 0;                      // the byte record is held in registers
@@ -117,19 +119,21 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     //      (vmcnt is in-order: waiting for the older table loads does not wait for the younger state loads).
     STAMP(0);
     constexpr int DM = DT > 0 ? DT : GW_MAX_DEVICES;
-    constexpr GwBlobLayout LM(DM);
-    const GwBlobLayout L(D);
-    const int n_ch = L.lds_total >> 4;                   // 16-byte chunks
+    constexpr GwStripeLayout LM(DM);
+    const GwStripeLayout L(D);
+    constexpr int MAX_CH = LM.staged_chunks(GW_MAX_NSTATES);
+    const int n_ch = n_stage < MAX_CH ? n_stage : MAX_CH;    // 16-byte chunks: mi + the stripes of the states this handle has
     const int tid = threadIdx.x;
     constexpr int nthr = 64;                                             // the launchers' block size
-    constexpr int PER_FULL = ((LM.lds_total >> 4) + 63) / 64;            // chunks per thread
-    constexpr int PER = (DT > 0 && PER_FULL <= 8) ? PER_FULL : 1;
-    constexpr bool one_pass = DT > 0 && PER_FULL <= 8;
+    constexpr int PER_FULL = (MAX_CH + 63) / 64;                         // chunks per thread, all 16 states
+    constexpr int PER = (DT > 0 && PER_FULL <= 11) ? PER_FULL : 1;
+    constexpr bool one_pass = DT > 0 && PER_FULL <= 11;
     // (one pass: the LDS image is padded to whole rounds of 64 chunks and every lane loads and writes its chunk of every round
-    //  unconditionally -- lanes past the tables' end re-read chunk 0 into the padding -- so that the staging is straight-line
+    //  unconditionally -- lanes past the staged prefix re-read chunk 0 (one broadcast request) into the padding; skipping
+    //  such rounds with a wave-uniform test measured no better -- so that the staging is straight-line
     //  code: with a guard per chunk it was a chain of exec-mask regions, and the scalar loads of the remaining kernel
     //  arguments ended up behind the first wait for the tables instead of in front of it)
-    __shared__ __attribute__((aligned(16))) uint8_t s_blob[one_pass ? PER * 64 * 16 : LM.lds_total];
+    __shared__ __attribute__((aligned(16))) uint8_t s_blob[one_pass ? PER * 64 * 16 : MAX_CH * 16];
     uint4 r_ch[PER];
     if (one_pass) {
 #pragma unroll
@@ -192,12 +196,17 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     // (the action is used unconditionally here, so that its loads stay at the top with the others: with every use inside
     //  `if (live)` the compiler sank them into that block, behind the waits above)
     PIN_V(d); PIN_V(du);
-    const double* s_ber = reinterpret_cast<const double*>(s_blob + L.ber);
     const uint2* s_mi = reinterpret_cast<const uint2*>(s_blob + L.mi);
-    const uint8_t* s_h1 = s_blob + L.h1;
-    const uint8_t* s_rr = s_blob + L.r1;
-    const uint8_t* g_h2 = st.blob + L.h2;               // HBM/L2
-    const uint8_t* s_cls = s_blob + L.cls;
+    const uint8_t* s_st = s_blob + L.s0;                // stripe of state s at s_st + s * L.stripe
+    const uint8_t* g_h2 = st.blob + L.h2;               // HBM/L2: [s][j][d]
+    const uint32_t STR = (uint32_t)L.stripe, DD = (uint32_t)D;
+    auto t_ber0 = [&](uint32_t dd, uint32_t ss) { return *reinterpret_cast<const double*>(s_st + ss * STR + (uint32_t)L.ber0 + dd * 8u); };
+    auto t_ber1 = [&](uint32_t dd, uint32_t ss) { return *reinterpret_cast<const double*>(s_st + ss * STR + (uint32_t)L.ber1 + dd * 8u); };
+    auto t_h1 = [&](uint32_t j, uint32_t ss) { return (uint32_t)s_st[ss * STR + (uint32_t)L.h1 + j]; };
+    auto t_r1 = [&](uint32_t dd, uint32_t ss) { return (uint32_t)s_st[ss * STR + (uint32_t)L.r1 + dd]; };
+    auto t_cls0 = [&](uint32_t dd, uint32_t ss) { return (uint32_t)s_st[ss * STR + (uint32_t)L.cls0 + dd]; };
+    auto t_cls1 = [&](uint32_t dd, uint32_t ss) { return (uint32_t)s_st[ss * STR + (uint32_t)L.cls1 + dd]; };
+    auto t_h2 = [&](uint32_t j, uint32_t dd, uint32_t ss) { return (uint32_t)g_h2[(ss * DD + j) * DD + dd]; };
 
     if (live) {
         uint32_t rvm = ip.z;
@@ -262,8 +271,8 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             bpp.t0 = ip.x; bpp.c0 = ip.y;
             const GwBp* hist = st.bph + ((size_t)e << 7);
             // what the addressed sender / the RRM become after hearing the RRM / sender d once
-            const uint32_t s_d = s_h1[(uint32_t)(d * S) + s_d_old];
-            const uint32_t s_r1 = s_rr[(uint32_t)(d * S) + s_r_old];
+            const uint32_t s_d = t_h1((uint32_t)d, s_d_old);
+            const uint32_t s_r1 = t_r1((uint32_t)d, s_r_old);
             const uint2 mi = s_mi[d];
             // ... and every other sender j: after the announcement (n1), and after >= 1 data packet of d too (n2)
             uint32_t nb[PACKED ? 16 * NWC : 1];
@@ -273,15 +282,15 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 for (int b = 0; b < 16 * NWC; ++b) nb[b] = (word_of(qw[b >> 4], (b >> 2) & 3) >> ((b & 3) * 8)) & 0xffu;
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    n1[i] = s_h1[(uint32_t)(i * S) + nb[DT + i]];
-                    n2[i] = g_h2[(uint32_t)((i * DT + d) * S) + nb[DT + i]];
+                    n1[i] = t_h1((uint32_t)i, nb[DT + i]);
+                    n2[i] = t_h2((uint32_t)i, (uint32_t)d, nb[DT + i]);
                     mlt[i] = s_mi[i].x;
                 }
             }
-            const double ber_a = s_ber[(uint32_t)(d * S) + s_d];
-            const uint32_t cls_a = s_cls[(uint32_t)(d * S) + s_d];
-            const double ber_x1 = s_ber[(uint32_t)((D + d) * S) + s_r1];
-            const uint32_t cls_x1 = s_cls[(uint32_t)((D + d) * S) + s_r1];
+            const double ber_a = t_ber0((uint32_t)d, s_d);
+            const uint32_t cls_a = t_cls0((uint32_t)d, s_d);
+            const double ber_x1 = t_ber1((uint32_t)d, s_r1);
+            const uint32_t cls_x1 = t_cls1((uint32_t)d, s_r1);
             uint32_t s_r = s_r_old;
             const uint32_t mult_d = mi.x;
             const uint32_t inv16_d = mi.y;
@@ -442,7 +451,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                     const uint32_t l0 = st.qb[oq + (uint32_t)i];
                     const uint32_t s0 = st.qb[oq + (uint32_t)(D + i)];
                     const uint32_t s1 = !idem ? heard_slow(i, s0)
-                                              : (n_data ? g_h2[(uint32_t)((i * D + d) * S) + s0] : s_h1[(uint32_t)(i * S) + s0]);
+                                              : (n_data ? t_h2((uint32_t)i, (uint32_t)d, s0) : t_h1((uint32_t)i, s0));
                     st.qb[oq + (uint32_t)i] = (uint8_t)gw_len_after_ticks(l0, n_ticks, s_mi[i].x, k);
                     if (s1 != s0) st.qb[oq + (uint32_t)(D + i)] = (uint8_t)s1;
                 }
@@ -489,8 +498,10 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
 //    device-visible memory (tools/launch_floor.hip); the short block takes env.step()'s enqueue below the kernel's time
 //    in every phase.
 #define GW_LEAD_PARAMS uint32_t* __restrict__ ip, double* __restrict__ tw, uint32_t* __restrict__ tk, uint8_t* __restrict__ qb, \
-                       const int32_t* __restrict__ device, const int32_t* __restrict__ duration, uint32_t n_envs, int32_t n_dev
-#define GW_LEAD_ARGS(st_) (st_).ip, (st_).tw, (st_).tk, (st_).qb, device, duration, (uint32_t)(st_).N, (int32_t)(st_).D
+                       const int32_t* __restrict__ device, const int32_t* __restrict__ duration, uint32_t n_envs, uint32_t dev_stage
+// dev_stage: sender count | chunks of the tables to stage << 8 (one argument: the preload window holds 14 dwords)
+#define GW_LEAD_ARGS(st_) (st_).ip, (st_).tw, (st_).tk, (st_).qb, device, duration, (uint32_t)(st_).N, \
+                          ((uint32_t)(st_).D | ((uint32_t)(st_).stage_chunks << 8))
 // (read through the CONSTANT address space: nothing writes the header while a step kernel runs, and as constant-space
 //  loads the reads become scalar loads that the compiler may issue anywhere -- in particular at the top of the wave,
 //  in front of the fence that follows the table staging; as plain global loads they stayed behind that fence and their
@@ -523,11 +534,12 @@ template <int DT, int MODE>
 __global__ __launch_bounds__(64) void ct_step_sfx_kernel(GW_LEAD_PARAMS, int32_t* __restrict__ obs, float* __restrict__ reward,
                                                         uint8_t* __restrict__ done, uint8_t* __restrict__ fb)
 {
+    const int n_dev = (int)(dev_stage & 0xffu);
     const GwState st = hdr_state<DT>(ip, tw, tk, qb, n_envs, n_dev);
     const GwDevConst c = hdr_const<DT>(ip, n_dev);
     double now_new;
     bool live;
-    ct_step_sfx_body<DT, true, MODE>(st, c, device, duration, obs, reward, done, fb, now_new, live);
+    ct_step_sfx_body<DT, true, MODE>(st, c, device, duration, obs, reward, done, fb, (int)(dev_stage >> 8), now_new, live);
 }
 
 // ---- BASELINE config 4: env.step() of the pendulum env in ONE launch ------------------------------------------------
@@ -543,6 +555,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GW_LEAD_PARAMS, GwPlantDe
                                                        int32_t* __restrict__ obs, float* __restrict__ reward,
                                                        double* __restrict__ angle_deg)
 {
+    const int n_dev = (int)(dev_stage & 0xffu);
     const GwState st = hdr_state<2>(ip, tw, tk, qb, n_envs, n_dev);
     const GwDevConst c = hdr_const<2>(ip, n_dev);
     constexpr int EPW = HALF ? 32 : 64;                  // envs per wave
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(64) void pend_step_kernel(GW_LEAD_PARAMS, GwPlantDe
 
     double now_new;
     bool live;
-    ct_step_sfx_body<2, false, MODE, HALF>(st, c, device, duration, nullptr, nullptr, nullptr, nullptr, now_new, live);
+    ct_step_sfx_body<2, false, MODE, HALF>(st, c, device, duration, nullptr, nullptr, nullptr, nullptr, (int)(dev_stage >> 8), now_new, live);
 #ifdef GW_EXP_NO_EPILOGUE
     if (now_new >= 0.0) return;
 #endif

@@ -503,7 +503,31 @@ int gw_create(const gw_config* cfg, gw_env** out)
                     blob[(size_t)L.h2 + ((size_t)j * D + dd) * S + s0] = (j == dd) ? a : tr[((size_t)j * R + dd) * S + a];
             }
         }
-        HIP_TRY_D(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        if (!st.ip) {                               // explicit mode: the generic kernel's tables (GwBlobLayout)
+            HIP_TRY_D(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        } else {                                    // suffix mode: the same numbers state-major (GwStripeLayout), in the ip block's header
+            const GwStripeLayout T(D);
+            std::vector<uint8_t> sb((size_t)T.total, 0);
+            int nst = 1;
+            for (int r = 0; r < R; ++r) nst = env->tab.nstates[r] > nst ? env->tab.nstates[r] : nst;
+            if (nst > S) nst = S;
+            for (int j = 0; j < D; ++j) {
+                memcpy(sb.data() + T.mi + (size_t)j * 8, blob.data() + L.mi + (size_t)j * 8, 8);
+                for (int s0 = 0; s0 < S; ++s0) {
+                    uint8_t* stripe = sb.data() + T.s0 + (size_t)s0 * T.stripe;
+                    memcpy(stripe + T.ber0 + (size_t)j * 8, &b2[(size_t)j * S + s0], 8);
+                    memcpy(stripe + T.ber1 + (size_t)j * 8, &b2[((size_t)D + j) * S + s0], 8);
+                    stripe[T.h1 + j] = blob[(size_t)L.h1 + (size_t)j * S + s0];
+                    stripe[T.r1 + j] = blob[(size_t)L.r1 + (size_t)j * S + s0];
+                    stripe[T.cls0 + j] = c2[(size_t)j * S + s0];
+                    stripe[T.cls1 + j] = c2[((size_t)D + j) * S + s0];
+                    for (int dd = 0; dd < D; ++dd)
+                        sb[(size_t)T.h2 + ((size_t)s0 * D + j) * D + dd] = blob[(size_t)L.h2 + ((size_t)j * D + dd) * S + s0];
+                }
+            }
+            st.stage_chunks = T.staged_chunks(env->tab.overflow ? S : nst);
+            HIP_TRY_D(hipMemcpy(d_blob, sb.data(), sb.size(), hipMemcpyHostToDevice));
+        }
     }
     if (st.totals) HIP_TRY_D(hipMemset(st.totals, 0, (size_t)st.n_slots * GW_T_COUNT * sizeof(unsigned long long)));
     if (st.runs) HIP_TRY_D(hipMemset(st.runs, 0, (size_t)N * D * GW_RING_PHYS * sizeof(uint64_t)));

@@ -7,7 +7,9 @@
 
 #define GW_RING_PHYS      128          // physical ring slots per (env, sender); logical capacity GW_QUEUE_CAP
 #define GW_RING_MASK      (GW_RING_PHYS - 1)
+#ifndef GW_MAX_NSTATES
 #define GW_MAX_NSTATES    16           // rx-power (noise residue) states per radio, see gw_tables.cpp
+#endif
 
 // Constants the kernels need, resident in device global memory (read through
 // the scalar cache: every field is wave-uniform).
@@ -44,6 +46,7 @@ struct GwState {
     int64_t   N;
     int32_t   D, R;     // host-side copies of the constants (launch sizing)
     int32_t   block;    // threads per workgroup of the step kernel
+    int32_t   stage_chunks;  // suffix mode: 16-byte chunks of the state-major tables a step kernel stages in LDS (GwStripeLayout)
     double*   now;        // [N]        simulated time (SimMan.now)
     double*   wake;       // [N]        next counter tick (all senders tick in lock-step)
     uint32_t* counter;    // [N]        sender.counter (identical for all senders of an env)
@@ -107,9 +110,30 @@ struct GwBlobLayout {
           total(h2 + D * D * GW_MAX_NSTATES) {}
 };
 
+// The same tables for the default (suffix-queue) step kernels, STATE-MAJOR: after the multiplicity table one stripe per noise
+// state s, holding everything the step looks up for that state --
+//     [ mi u32[D][2] | stripe 0 | stripe 1 | ... | stripe 15 | h2 u8[S][D][D] ]
+//     stripe s = { ber0 f64[D] (sender d hears the RRM), ber1 f64[D] (the RRM hears d), h1 u8[D], r1 u8[D], cls0 u8[D], cls1 u8[D] }
+// -- so that a step kernel stages only the prefix that covers the states this handle's layout actually has (3 at D = 2, 4 at
+// D = 4, 6 at D = 16, 8 at D = 32 with the default geometry; 16 is the limit): 352 bytes instead of 1.3 KB at D = 4, 2 KB instead
+// of 5.2 KB at D = 16, through an L1 path that four waves per CU share at 64 bytes per clock.
+struct GwStripeLayout {
+    int mi, s0, stripe, ber0, ber1, h1, r1, cls0, cls1, h2, total;
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    constexpr explicit GwStripeLayout(int D)
+        : mi(0), s0((8 * D + 15) / 16 * 16), stripe((20 * D + 15) / 16 * 16), ber0(0), ber1(8 * D), h1(16 * D), r1(17 * D),
+          cls0(18 * D), cls1(19 * D), h2(s0 + GW_MAX_NSTATES * stripe), total(h2 + D * D * GW_MAX_NSTATES) {}
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    constexpr int staged_chunks(int nstates) const { return (s0 + nstates * stripe + 15) / 16; }   // 16-byte chunks to put in LDS
+};
+
 // In the default (suffix-queue) mode the step tables, the handle's GwDevConst and its GwState live in the SAME allocation as
 // the `ip` records, in a header of gw_blob_header(D) bytes in front of them (gw_api.cpp fills it at gw_create):
-//     [ blob (GwBlobLayout) | GwDevConst at gw_hdr_cst_off | GwState at gw_hdr_st_off | pad to 256 ] [ ip records ... ]
+//     [ tables (GwStripeLayout) | GwDevConst at gw_hdr_cst_off | GwState at gw_hdr_st_off | pad to 256 ] [ ip records ... ]
 // The per-step kernels get `ip` as a preloaded leading argument and derive everything else from it.  Their argument block
 // shrinks from 1.2 KB (both structs by value) to under 100 bytes: the runtime writes a launch's arguments into
 // device-visible memory, and for 1.2 KB that alone took 3.6 us of the host's 5.5 us per launch (tools/launch_floor.hip).
@@ -118,7 +142,7 @@ struct GwBlobLayout {
 #else
 #define GW_HDC
 #endif
-GW_HDC constexpr int gw_hdr_cst_off(int D) { return (GwBlobLayout(D).total + 16 + 15) / 16 * 16; }
+GW_HDC constexpr int gw_hdr_cst_off(int D) { return (GwStripeLayout(D).total + 16 + 15) / 16 * 16; }
 GW_HDC constexpr int gw_hdr_st_off(int D) { return gw_hdr_cst_off(D) + ((int)sizeof(GwDevConst) + 15) / 16 * 16; }
 GW_HDC constexpr int gw_blob_header(int D) { return (gw_hdr_st_off(D) + (int)sizeof(GwState) + 255) / 256 * 256; }
 

@@ -738,23 +738,60 @@ __global__ void ct_clear_flags_kernel(GwState st)
     if (st.totals && e < st.n_slots) st.totals[(size_t)e * GW_T_COUNT + GW_T_FLAGS] = 0ull;
 }
 
+// The step kernel's arguments as the one block the runtime copies (same order and natural alignment as the kernel's
+// parameter list: 88 bytes).  Launched through hipModuleLaunchKernel with this block instead of `<<< >>>`: the triple-chevron
+// path looks the kernel up by its host address and copies twelve arguments one by one, 0.36 us more per launch on the host
+// (tools/launch_floor.hip: 3.31 -> 2.95 us) -- and the host's enqueue rate is what limits the light phases of a rollout.
+struct StepArgs {
+    uint32_t* ip; double* tw; uint32_t* tk; uint8_t* qb; const int32_t* device; const int32_t* duration;
+    uint32_t n_envs, dev_stage;
+    int32_t* obs; float* reward; uint8_t* done; uint8_t* fb;
+};
+static_assert(sizeof(StepArgs) == 88, "StepArgs must mirror ct_step_sfx_kernel's parameter list");
+
+template <int DT, int MODE>
+hipFunction_t step_function()
+{
+    static hipFunction_t fn[16] = {};                  // per device: a module's functions belong to the device it was loaded on
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!fn[dev]) {
+        hipFunction_t f = nullptr;
+        if (hipGetFuncBySymbol(&f, reinterpret_cast<const void*>(&ct_step_sfx_kernel<DT, MODE>)) != hipSuccess) { (void)hipGetLastError(); f = nullptr; }
+        fn[dev] = f;
+    }
+    return fn[dev];
+}
+
+template <int DT, int MODE>
+void launch_mode(const GwState& st, unsigned grid, const int32_t* device, const int32_t* duration,
+                 int32_t* obs, float* reward, uint8_t* done, uint8_t* fb, hipStream_t stream)
+{
+    const uint32_t dev_stage = (uint32_t)st.D | ((uint32_t)st.stage_chunks << 8);
+    if (hipFunction_t f = step_function<DT, MODE>()) {
+        StepArgs a = {st.ip, st.tw, st.tk, st.qb, device, duration, (uint32_t)st.N, dev_stage, obs, reward, done, fb};
+        size_t size = sizeof a;
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+        (void)hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, stream, nullptr, extra);
+        return;
+    }
+    hipLaunchKernelGGL((ct_step_sfx_kernel<DT, MODE>), dim3(grid), dim3(64), 0, stream, st.ip, st.tw, st.tk, st.qb, device, duration,
+                       (uint32_t)st.N, dev_stage, obs, reward, done, fb);
+}
+
 template <int DT>
 int launch(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
            int32_t* obs, float* reward, uint8_t* done, uint8_t* fb, void* stream, bool below_limits)
 {
-    const unsigned blk = 64u;                          // the kernel's compile-time block size
-    const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
+    const unsigned grid = (unsigned)((st.N + 63) / 64);  // the kernel's compile-time block size is 64
     // every exact fast form validated for this handle (gw_create): the instantiation without their fallbacks -- and, when
     // the host can rule out that any env reaches their validity limits in this launch, without the per-lane limit tests
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.idem_states && cst.fast_ticks;
-#define GW_STEP(MODE_) hipLaunchKernelGGL((ct_step_sfx_kernel<DT, MODE_>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, GW_LEAD_ARGS(st), \
-                                          obs, reward, done, fb)
     switch (fast ? (below_limits ? 2 : 1) : 0) {
-    case 2:  GW_STEP(2); break;
-    case 1:  GW_STEP(1); break;
-    default: GW_STEP(0); break;
+    case 2:  launch_mode<DT, 2>(st, grid, device, duration, obs, reward, done, fb, (hipStream_t)stream); break;
+    case 1:  launch_mode<DT, 1>(st, grid, device, duration, obs, reward, done, fb, (hipStream_t)stream); break;
+    default: launch_mode<DT, 0>(st, grid, device, duration, obs, reward, done, fb, (hipStream_t)stream); break;
     }
-#undef GW_STEP
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 

@@ -146,7 +146,20 @@ int main(int argc, char** argv)
         const double t_small = enqueue_us([&] { hipLaunchKernelGGL(k_small, dim3(1024), dim3(64), 0, s, pa, (double*)a, pa, (unsigned char*)a,
                                                                    (const int*)a, (const int*)a, 65536u, 4, (int*)a, (float*)a, (unsigned char*)a); }, 64, s);
         const double t_one = enqueue_us([&] { hipLaunchKernelGGL(k_one, dim3(1024), dim3(64), 0, s, pa); }, 64, s);
-        printf("host enqueue per launch: one pointer argument %.2f us | 11 scalar arguments (80 B) %.2f us\n", t_one, t_small);
+        double t_small_mod = -1;
+        {
+            hipFunction_t fs = nullptr;
+            if (hipGetFuncBySymbol(&fs, (const void*)k_small) == hipSuccess && fs) {
+                struct SArgs { unsigned* a; double* b; unsigned* c; unsigned char* d; const int* e; const int* f; unsigned n; int nd; int* o; float* r; unsigned char* dn; } sa;
+                sa.a = pa; sa.b = (double*)a; sa.c = pa; sa.d = (unsigned char*)a; sa.e = (const int*)a; sa.f = (const int*)a; sa.n = 65536u; sa.nd = 4;
+                sa.o = (int*)a; sa.r = (float*)a; sa.dn = (unsigned char*)a;
+                size_t ssz = sizeof sa;
+                void* ex[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &sa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ssz, HIP_LAUNCH_PARAM_END};
+                t_small_mod = enqueue_us([&] { (void)hipModuleLaunchKernel(fs, 1024, 1, 1, 64, 1, 1, 0, s, nullptr, ex); }, 64, s);
+                CK(hipGetLastError());
+            }
+        }
+        printf("host enqueue per launch: one pointer argument %.2f us | 11 scalar arguments (80 B) %.2f us | the same through hipModuleLaunchKernel + one buffer %.2f us\n", t_one, t_small, t_small_mod);
         printf("host enqueue per launch: empty kernel %.2f us | 11 arguments, 1.2 KB, <<<>>> %.2f us | same through hipModuleLaunchKernel + one buffer %.2f us\n",
                t_empty, t_chevron, t_mod);
     }

@@ -269,8 +269,8 @@ def main():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev[0].record()
+        ev[0].record()                              # (the stream-time marker: enqueued, not waited for, before the clock starts, so
+        t0 = time.perf_counter()                    #  that its 2 us of host time are not billed to the K steps it brackets)
         for i in range(W, W + K):
             one(i)
         ev[1].record()

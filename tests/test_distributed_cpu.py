@@ -136,11 +136,20 @@ def _chunk_worker(rank, world, port, total, D, K, chunk, seed, out_dir):
             cg.pending[b].wait()
             got.append(cg.result(b).clone())                     # uint8[world][steps][n]
 
+        one_call = (K + chunk) % 2 == 1                          # half of the cases through the one-call-per-step protocol
+        views = cg.begin() if one_call else None
         for k in range(K):
-            obs, rew, done = cg.slot()
+            if one_call:                                         # begin() / advance(): what bench.py uses
+                obs, rew, done = views[0], views[1], views[2]
+            else:                                                # slot() / stepped()
+                obs, rew, done = cg.slot()
             o, r, d = shard.step(dev[k, lo:hi], dur[k, lo:hi])
             obs.copy_(torch.from_numpy(o)); rew.copy_(torch.from_numpy(r)); done.copy_(torch.from_numpy(d))
-            b = cg.stepped()
+            if one_call:
+                views = cg.advance()
+                b = ((k // chunk) % cg.depth) if (k + 1) % chunk == 0 else None
+            else:
+                b = cg.stepped()
             if b is not None:
                 collect(b)
         tail = K % chunk

@@ -175,7 +175,7 @@ def _chunk_worker(rank, world, port, total, D, K, chunk, seed, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,chunk", [(12, 4), (10, 4), (3, 8)])
+@pytest.mark.parametrize("K,chunk", [(12, 4), (10, 4), (3, 8), (13, 4), (9, 3)])
 def test_two_rank_chunked_feedback_gather(tmp_path, K, chunk):
     world, total, D = 2, 64, 4
     port = _free_port()

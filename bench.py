@@ -3,7 +3,10 @@
 bench.py -- env.step()/s of the vectorised CounterTraffic band-assignment env on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either under an external launcher (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or plain `python bench.py --gpus N ...`:
+    then THIS process -- before it has imported torch or touched HIP -- starts N fresh rank processes of itself
+    (launch_ranks), relays rank 0's one JSON line and exits non-zero if any rank does.
 
 A "step" is ONE env.step() of every environment of the batch: one launch of the HIP step kernel over
 65 536 envs x 4 devices per GPU (BASELINE.json configs[1]).  Actions are synthetic: a counter-based
@@ -17,6 +20,16 @@ time once (the driver's --steps 20 is 0.2 ms), the window is REPEATED until >= 0
 have accumulated; every repeat starts from a reset, so every repeat times the same step indices after a
 reset (`timed_step_indices_after_reset`).  `value` = all env-steps of all timed regions / the sum over
 windows of the slowest rank's wall time.  Rank 0 prints ONE JSON line.
+
+At N > 1 every env.step() of the timed region is followed by the end-of-step observation gather the north star names:
+ONE RCCL all-gather of the rank's 9*N-byte (obs, reward, done) record, ordered on the step's stream so that step k+1 is
+launched behind it -- every rank holds every env's feedback of step k before step k+1 runs, as the reference's caller
+acts on every observation (agents/dqn_counter_traffic.py:63-70).  `value` at N > 1 is THAT form (`config.obs_gather` =
+"per-step").  Two relaxed forms are reported beside it as named secondaries with the lateness they trade for speed:
+`pipelined_gather` (the gather of step k overlaps step k+1: observations one step late) and `chunked_gather` (one byte
+per env-step, one all-gather per 16 / 64 steps: up to a chunk late).  The line's `ranks` object is the evidence that RCCL
+met N distinct GPUs: world size as torch.distributed reports it, the PCI bus id and device name of every rank
+(all-gathered), the backend and its version.
 
   roofline     HBM bound.  `achieved` = SURVEY 8d's ALGORITHMIC bytes per launch / average launch duration (HIP events
                on the launch stream around each timed region, / K), `frac` = achieved / 8 TB/s.  Algorithmic bytes per
@@ -137,6 +150,103 @@ def emit(line):
         os.write(_REAL_STDOUT, data)
 
 
+def _free_port():
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def launch_ranks(n, child_argv, timeout=None, env=None, grace=10.0):
+    """Start `n` fresh rank processes of `child_argv` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in
+    their environment), relay what rank 0 writes to its stdout, and return the job's exit code: 0 if every rank exited 0,
+    else the first non-zero code seen (the other ranks are then terminated -- by their exact PIDs -- after `grace` seconds,
+    since a rank whose peer died would wait in its next collective for ever).  The ranks are CHILD processes, never an exec
+    of this one; the caller must not have initialised HIP (bench.py calls this before importing torch).  The other ranks'
+    stdout goes to this process's stderr, so that stdout carries rank 0's single JSON line and nothing else."""
+    import subprocess
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in base:
+        base["MASTER_PORT"] = str(_free_port())
+    base["WORLD_SIZE"] = str(n)
+    base["LOCAL_WORLD_SIZE"] = str(n)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base["GW_BENCH_SELF_LAUNCHED"] = "1"
+    procs = []
+    try:
+        for r in range(n):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+            procs.append(subprocess.Popen(list(child_argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(),
+                                          stderr=None, cwd=os.getcwd()))
+        # rank 0's stdout is read by a thread so that a full pipe can never stall it
+        import threading
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = None if not timeout else time.monotonic() + float(timeout)
+        rc, failed_at = 0, None
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad and rc == 0:
+                rc, failed_at = bad[0], time.monotonic()
+                sys.stderr.write("bench.py: rank(s) %s exited with %s; stopping the job\n"
+                                 % ([i for i, c in enumerate(codes) if c not in (None, 0)], bad))
+            if all(c is not None for c in codes):
+                break
+            if deadline is not None and time.monotonic() > deadline and rc == 0:
+                rc, failed_at = 124, time.monotonic() - grace
+                sys.stderr.write("bench.py: ranks still running after %.0f s; stopping the job\n" % float(timeout))
+            if failed_at is not None:
+                late = time.monotonic() - failed_at
+                for p_ in procs:
+                    if p_.poll() is None:
+                        if late > 2 * grace:
+                            p_.kill()
+                        elif late > grace:
+                            p_.terminate()
+            time.sleep(0.05)
+        reader.join(timeout=5.0)
+        out = b"".join(c for c in chunks if c)
+        if out:
+            os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, out)
+        return rc
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=5.0)
+            except Exception:
+                pass
+
+
+def device_identity(torch, index):
+    """What tells two GPUs apart: the PCI bus id HIP reports for the device this rank computes on, its name and (when torch
+    exposes it) its UUID."""
+    import ctypes
+    ident = {"index": int(index), "name": torch.cuda.get_device_name(index), "pci_bus_id": None}
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+            ident["pci_bus_id"] = buf.value.decode()
+    except Exception as exc:                                   # evidence only: never costs the measurement
+        ident["pci_bus_id_error"] = repr(exc)
+    props = torch.cuda.get_device_properties(index)
+    if ident["pci_bus_id"] is None and hasattr(props, "pci_bus_id"):
+        ident["pci_bus_id"] = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+    if hasattr(props, "uuid"):
+        ident["uuid"] = str(props.uuid)
+    ident["pid"] = os.getpid()
+    ident["visible"] = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    return ident
+
+
 def main():
     global _REAL_STDOUT
     if _REAL_STDOUT is None:
@@ -161,6 +271,12 @@ def main():
     ap.add_argument("--no-steady", action="store_true", help="skip the secondary no-reset steady-state measurement")
     ap.add_argument("--no-secondaries", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher gave us ranks, so start them -- from a process that has not
+        # imported torch or made a HIP call -- and relay rank 0's line
+        rc = launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                          timeout=float(os.environ.get("GW_BENCH_LAUNCH_TIMEOUT", "1700")))
+        sys.exit(rc)
     if args.no_secondaries:
         args.no_rollout = args.no_graph = args.no_steady = True
     if args.config == 3:
@@ -181,7 +297,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with --nproc-per-node %d, or with no "
+                         "launcher at all (it then starts its own ranks)" % (args.gpus, world, args.gpus))
     # GW_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
     # host-side collectives); the driver's runs use the default, RCCL with one GPU per rank.
     backend = os.environ.get("GW_BENCH_BACKEND", "nccl")
@@ -208,53 +325,73 @@ def main():
     N, D, K, W = args.envs, args.devices, args.steps, args.warmup
     env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, device=dev_t)
 
-    # outputs as three views of ONE packed record buffer so that a per-step observation
-    # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
-    from gymwipe_amd.sharding import ChunkedFeedbackGather, ObservationGather, StepRecord
-    pipe = None
-    # steps per all-gather: 64 for long timed regions; a short region (the driver's 20 steps) gathers every 16 steps, so that
-    # most of its feedback travels while the region is still stepping and the flush at its end -- whose latency no later
-    # step can hide -- carries only the last few rows
-    GATHER_EVERY = RESET_EVERY if args.steps >= 2 * RESET_EVERY else max(1, min(16, args.steps))
-    if multi and not args.no_gather:
+    # ---- who is in the job (the line's `ranks` object): world size as the process group reports it and every rank's GPU ----
+    ranks_info = None
+    if multi:
+        mine = device_identity(torch, local)
+        mine["rank"] = rank
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        bus = [e.get("pci_bus_id") for e in everyone]
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                      "devices": bus, "distinct_devices": len(set(b for b in bus if b)),
+                      "device_names": sorted(set(e.get("name") for e in everyone)),
+                      "per_rank": everyone,
+                      "launcher": "bench.py launch_ranks (self-started child processes)" if os.environ.get("GW_BENCH_SELF_LAUNCHED")
+                                  else ("external (RANK/WORLD_SIZE from the environment)" if "RANK" in os.environ and world > 1 else "single process")}
         if backend == "nccl":
-            # pack=None: the step kernel writes each step's one-byte row itself (gw_step_fb), no packing launch per chunk
-            pipe = ChunkedFeedbackGather(N, dev_t, None, world, chunk=GATHER_EVERY)
-        else:                                                    # rehearsal: pack on the GPU, gather on the host
-            stage = torch.empty((GATHER_EVERY, N), dtype=torch.uint8, device=dev_t)
+            try:
+                ranks_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as exc:
+                ranks_info["rccl_version"] = repr(exc)
+        if backend == "nccl" and ranks_info["distinct_devices"] != ranks_info["world_size"] and world > 1:
+            raise SystemExit("RCCL job of %d ranks sees %d distinct GPUs (%s): one GPU per rank is the contract"
+                             % (world, ranks_info["distinct_devices"], bus))
 
-            def pack_to_host(o, r, d, out):
-                env.pack_feedback(o, r, d, stage[:o.shape[0]])
-                out.copy_(stage[:o.shape[0]])
-            pipe = ChunkedFeedbackGather(N, dev_t, pack_to_host, world, chunk=GATHER_EVERY)
-            pipe.packed = [torch.zeros((GATHER_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
-            pipe.gathered = [torch.zeros((world, GATHER_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
+    # outputs as three views of ONE packed record buffer so that the per-step observation
+    # gather is a single RCCL all-gather without a packing kernel (gymwipe_amd/sharding.py)
+    from gymwipe_amd.sharding import ChunkedFeedbackGather, ObservationGather, PipelinedGather, StepRecord
     rec = StepRecord(N, dev_t)
     env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
+    gathering = multi and not args.no_gather
+    # steps per all-gather of the CHUNKED secondary: 64 for long timed regions; a short region (the driver's 20 steps) gathers
+    # every 16 steps, so that most of its feedback travels while the region is still stepping
+    GATHER_EVERY = RESET_EVERY if args.steps >= 2 * RESET_EVERY else max(1, min(16, args.steps))
+
+    # the headline's exchange at N > 1: ONE all-gather of this rank's 9*N-byte record after EVERY step, ordered on the step's stream
+    step_gather = None
+    gather_entry = None
+    if gathering:
+        if backend == "nccl":
+            og = ObservationGather(rec, world)
+            step_gather, gather_entry = og.step_done, og.entry
+        else:                                                    # rehearsal: host-side collective (ranks share a GPU)
+            host_rec = torch.zeros(rec.nbytes, dtype=torch.uint8)
+            host_out = torch.zeros(world * rec.nbytes, dtype=torch.uint8)
+            gather_entry = "all_gather_into_tensor on host copies (%s rehearsal)" % backend
+
+            def step_gather():
+                host_rec.copy_(rec.buf)
+                dist.all_gather_into_tensor(host_out, host_rec)
 
     # this rank's shard of the global action stream: envs [rank*N, (rank+1)*N), steps [0, W+K) of a window
     a_dev, a_dur = actions_torch(SEED, rank * N, (rank + 1) * N, 0, W + K, D, device=dev_t)
     acts = [{"device": a_dev[i], "duration": a_dur[i]} for i in range(W + K)]
 
-    fused_rows = pipe is not None and pipe._pack is None
-    views = [pipe.begin() if pipe is not None else None]
-
     from gymwipe_amd import StepOutputs
-    own = StepOutputs(rec.obs, rec.reward, rec.done)     # N = 1: every step writes the same record
+    own = StepOutputs(rec.obs, rec.reward, rec.done)     # every step writes the same record
 
-    def one(i):
-        if i % RESET_EVERY == 0:
-            env.reset()
-        if pipe is None:
+    if step_gather is None:
+        def one(i):
+            if i % RESET_EVERY == 0:
+                env.reset()
             env.step(acts[i], own)
-        elif fused_rows:                          # this step's outputs go into the current chunk record, its one-byte feedback
-            env.step(acts[i], views[0])           # row included (gw_step_fb): views[0] is the chunk slot's StepOutputs
-            views[0] = pipe.advance()             # chunk full: async all-gather over RCCL
-        else:                                     # rehearsal: typed outputs into the chunk record, packing kernel per chunk
-            v = views[0]
-            env._obs, env._rew, env._done = v[0], v[1], v[2]
-            env.step(acts[i])
-            views[0] = pipe.advance()
+    else:
+        def one(i):
+            if i % RESET_EVERY == 0:
+                env.reset()
+            env.step(acts[i], own)
+            step_gather()                             # step i+1 is launched behind the gather of step i's record
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
@@ -262,9 +399,6 @@ def main():
         """reset -> W warm-up steps -> K timed steps; returns (wall s, stream s, stats delta or None)."""
         for i in range(W):
             one(i)
-        if pipe is not None:
-            pipe.drain()                              # the warm-up steps' feedback leaves before the clock starts
-            views[0] = pipe.begin()
         s0 = env.stats() if with_stats else None   # (synchronises)
         if multi:
             dist.barrier()
@@ -274,10 +408,7 @@ def main():
         for i in range(W, W + K):
             one(i)
         ev[1].record()
-        if pipe is not None:
-            pipe.drain()                              # the job is done when the last gather has landed
-            views[0] = pipe.begin()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                      # (N > 1: the stream is ordered behind the last step's gather)
         wall = time.perf_counter() - t0
         if multi:
             dist.barrier()
@@ -322,6 +453,28 @@ def main():
     wall_total = sum(walls_max)
     stream_total = sum(streams)
     kern_avg_s = stream_total / (K * R)
+    kern_how = ("HIP events on the launch stream around each window's K timed launches, summed over the %d windows, / (K * windows) "
+                "(upper bound on the kernel's own duration: includes inter-launch gaps and the reset kernel every %d steps)"
+                % (R, RESET_EVERY))
+    if step_gather is not None:
+        # with a gather behind every step the stream time between the two events is step + collective; the KERNEL's average
+        # duration (what the roofline prices) comes from extra windows of the same K steps without the gather
+        saved, step_gather_saved = one, step_gather
+
+        def one(i):                                   # noqa: F811 -- window() looks `one` up at call time
+            if i % RESET_EVERY == 0:
+                env.reset()
+            env.step(acts[i], own)
+        ks, kn = 0.0, 0
+        for _ in range(max(3, min(R, int(0.1 / max(cal_stream, 1e-6)) or 1))):
+            _, st_s, _ = window(False)
+            ks, kn = ks + st_s, kn + 1
+        one = saved
+        kk = torch.tensor([ks / (K * kn)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+        kern_avg_s = float(kk.item())
+        kern_how = ("HIP events around %d extra windows of the same K timed launches WITHOUT the per-step gather (the headline's "
+                    "stream time per step, %.2f us, is step + collective), slowest rank" % (kn, stream_total / (K * R) * 1e6))
     # The K launches of a timed region run back-to-back on one stream, so (HIP event at the end - HIP event at the
     # start) / K is the average launch duration including inter-kernel gaps and the reset kernel every 64 steps: an
     # UPPER bound on the kernel's own time (event pairs around every launch add ~2.5 us each).
@@ -402,27 +555,8 @@ def main():
                 "what": "no reset for >= 64 steps before and during the timed steps: queues hold only packets too long "
                         "for any window, so a step is the announcement plus counter ticks"}
 
-    def secondary_per_step_gather():
-        """The literal end-of-step gather north_star names: every step's 9*N-byte (obs, reward, done) record all-gathered
-        before the next step is launched."""
-        env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
-        if backend == "nccl":
-            gather = ObservationGather(rec, world)
-            go = gather
-        else:                                                    # rehearsal: host-side collective
-            host_rec = torch.zeros(rec.nbytes, dtype=torch.uint8)
-            host_out = torch.zeros(world * rec.nbytes, dtype=torch.uint8)
-
-            def go():
-                host_rec.copy_(rec.buf)
-                dist.all_gather_into_tensor(host_out, host_rec)
-
-        def run():
-            for i in range(W + K):
-                if i % RESET_EVERY == 0:
-                    env.reset()
-                env.step(acts[i])
-                go()
+    def timed_job(run):
+        """One untimed pass, then one pass of the W+K-step window timed between barriers; the slowest rank's wall time."""
         run()
         torch.cuda.synchronize()
         dist.barrier()
@@ -432,14 +566,91 @@ def main():
         dist.barrier()
         el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=red_dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        el = float(el.item())
-        return {"env_steps_per_s": world * N * (W + K) / el, "ms_per_step": el / (W + K) * 1e3,
-                "bytes_per_rank_per_step": rec.nbytes,
-                "what": "one all_gather_into_tensor of the 9*N-byte step record per env.step(), issued on the step's stream "
-                        "(every rank sees every observation before the next step); the headline uses the chunked form "
-                        "(1 byte per env-step, one all-gather per %d steps, overlapped)" % GATHER_EVERY}
+        return float(el.item())
 
-    per_step = guarded(secondary_per_step_gather) if (multi and not args.no_gather) else None
+    def secondary_no_gather():
+        """The same ranks stepping their shards with NO exchange at all (what a learner co-located with each shard would see):
+        the difference to `value` is what the per-step gather costs."""
+        def run():
+            for i in range(W + K):
+                if i % RESET_EVERY == 0:
+                    env.reset()
+                env.step(acts[i], own)
+        el = timed_job(run)
+        return {"env_steps_per_s": world * N * (W + K) / el, "ms_per_step": el / (W + K) * 1e3, "observations_late_by_steps": None,
+                "what": "no observation gather: every rank keeps its shard's feedback to itself"}
+
+    def secondary_pipelined_gather():
+        """The per-step record gather, double-buffered: the all-gather of step k runs on RCCL's stream while step k+1's
+        kernel runs, and is waited for only before step k+2 overwrites its record."""
+        pg2 = PipelinedGather(N, dev_t, world)
+        outs = [StepOutputs(r.obs, r.reward, r.done) for r in pg2.records]
+        if backend != "nccl":                                  # rehearsal: host-side collective on copies of the records
+            host = [(torch.zeros(r.nbytes, dtype=torch.uint8), torch.zeros(world * r.nbytes, dtype=torch.uint8)) for r in pg2.records]
+
+        def run():
+            for i in range(W + K):
+                if i % RESET_EVERY == 0:
+                    env.reset()
+                j = pg2.k % pg2.depth
+                pg2.current()                                  # waits for the gather that last used record j
+                env.step(acts[i], outs[j])
+                if backend == "nccl":
+                    pg2.submit()
+                else:
+                    host[j][0].copy_(pg2.records[j].buf)
+                    pg2.pending[j] = dist.all_gather_into_tensor(host[j][1], host[j][0], async_op=True)
+                    pg2.k += 1
+            pg2.drain()
+        el = timed_job(run)
+        return {"env_steps_per_s": world * N * (W + K) / el, "ms_per_step": el / (W + K) * 1e3, "observations_late_by_steps": 1,
+                "bytes_per_rank_per_step": rec.nbytes,
+                "what": "the 9*N-byte record of step k all-gathered while step k+1 runs (two records, alternating): every rank "
+                        "holds step k's observations when step k+2 is launched, i.e. an agent acts on observations one step old"}
+
+    def secondary_chunked_gather():
+        """One byte per env-step, one all-gather per GATHER_EVERY steps, overlapped with the next chunk's stepping."""
+        if backend == "nccl":
+            # pack=None: the step kernel writes each step's one-byte row itself (gw_step_fb), no packing launch per chunk
+            pipe = ChunkedFeedbackGather(N, dev_t, None, world, chunk=GATHER_EVERY)
+        else:                                                    # rehearsal: pack on the GPU, gather on the host
+            stage = torch.empty((GATHER_EVERY, N), dtype=torch.uint8, device=dev_t)
+
+            def pack_to_host(o, r, d, out):
+                env.pack_feedback(o, r, d, stage[:o.shape[0]])
+                out.copy_(stage[:o.shape[0]])
+            pipe = ChunkedFeedbackGather(N, dev_t, pack_to_host, world, chunk=GATHER_EVERY)
+            pipe.packed = [torch.zeros((GATHER_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
+            pipe.gathered = [torch.zeros((world, GATHER_EVERY, N), dtype=torch.uint8) for _ in range(pipe.depth)]
+        fused_rows = pipe._pack is None
+
+        def run():
+            v = pipe.begin()
+            for i in range(W + K):
+                if i % RESET_EVERY == 0:
+                    env.reset()
+                if fused_rows:                        # this step's outputs go into the current chunk record, its one-byte feedback
+                    env.step(acts[i], v)              # row included (gw_step_fb): v is the chunk slot's StepOutputs
+                else:                                 # rehearsal: typed outputs into the chunk record, packing kernel per chunk
+                    env._obs, env._rew, env._done = v[0], v[1], v[2]
+                    env.step(acts[i])
+                v = pipe.advance()                    # chunk full: async all-gather
+            pipe.drain()                              # the job is done when the last gather has landed
+        el = timed_job(run)
+        env._obs, env._rew, env._done = rec.obs, rec.reward, rec.done
+        env._fb = None
+        return {"env_steps_per_s": world * N * (W + K) / el, "ms_per_step": el / (W + K) * 1e3,
+                "observations_late_by_steps": GATHER_EVERY, "bytes_per_rank_per_step": N, "steps_per_all_gather": GATHER_EVERY,
+                "entry": pipe.entry,
+                "what": "feedback compressed to ONE byte per env-step (lossless for the built-in interpreter; written by the step "
+                        "kernel itself, gw_step_fb) and all-gathered once per %d steps while the next chunk is stepped: an "
+                        "observation reaches the other ranks up to %d steps after its step" % (GATHER_EVERY, GATHER_EVERY)}
+
+    no_gather = pipelined = chunked = None
+    if gathering and not args.no_secondaries:
+        no_gather = guarded(secondary_no_gather)
+        pipelined = guarded(secondary_pipelined_gather)
+        chunked = guarded(secondary_chunked_gather)
     roll = guarded(secondary_rollout) if not args.no_rollout else None
     # graph replay at N = 1 only: stream capture next to a live RCCL communicator (whose watchdog thread queries
     # events) is a needless risk for a secondary figure
@@ -467,9 +678,7 @@ def main():
                 "min_bytes_per_env_step": state_bytes(D),
                 "frac_min_bytes": state_bytes(D) * N / kern_avg_s / HBM_PEAK,
                 "kernel": "ct_step_sfx_kernel", "kernel_avg_us": kern_avg_s * 1e6,
-                "how": "HIP events on the launch stream around each window's K timed launches, summed over the %d windows, / (K * windows) "
-                       "(upper bound on the kernel's own duration: includes inter-launch gaps and the reset kernel every %d steps)"
-                       % (R, RESET_EVERY),
+                "how": kern_how,
                 "algorithmic_bytes_per_launch": bytes_launch,
                 "algorithmic_bytes_per_env_step": bytes_launch / N,
                 "transmissions_per_env_step": txs / max(env_steps, 1),
@@ -495,18 +704,24 @@ def main():
                                    % (D, N, RESET_EVERY),
                        "envs_per_gpu": N, "devices": D, "global_envs": world * N,
                        "window": "reset -> %d warm-up steps -> %d timed steps, repeated %d times; each timed region bracketed by "
-                                 "barrier + synchronize; value = env-steps of all timed regions / sum of their wall times" % (W, K, R),
+                                 "barrier + synchronize; value = env-steps of all timed regions / sum of their wall times. The opening "
+                                 "HIP-event marker of a timed region is enqueued (not waited for) just before the wall clock starts, so "
+                                 "its ~2 us of host time (~0.1 us per step at K = 20) are outside the wall time" % (W, K, R),
                        "actions": "counter-based generator, seed %d (gymwipe_amd/actions.py), identical for the CPU baseline" % SEED,
-                       "obs_gather": pipe is not None,
-                       "parallelism": "independent env shards, one process per GPU; only exchange: end-of-step feedback "
-                                      "gather, 1 byte per env-step, one RCCL all-gather per %d steps overlapped with stepping "
-                                      "(the warm-up's rows are flushed before the clock starts, the last rows' gather ends inside the timed region)"
-                                      % GATHER_EVERY,
+                       "obs_gather": ("per-step" if gathering else False) if multi else False,
+                       "parallelism": ("independent env shards, one process per GPU, no data-path collective; only exchange: the "
+                                       "end-of-step observation gather -- one RCCL all-gather of each rank's %d-byte (obs, reward, done) "
+                                       "record after EVERY env.step(), on the step's stream, so that step k+1 is launched behind the "
+                                       "gather of step k (entry: %s)" % (rec.nbytes, gather_entry)) if gathering
+                                      else "independent env shards, one process per GPU, no exchange",
                        "launches_per_step": 1, "stream_ms_per_step": kern_avg_s * 1e3},
             "roofline": roof,
         }
-        if per_step is not None:
-            out["per_step_gather"] = per_step
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
+        if multi:
+            out["gather_forms"] = {"headline": "per-step (value): observations of step k on every rank before step k+1 is launched",
+                                   "no_gather": no_gather, "pipelined_gather": pipelined, "chunked_gather": chunked}
         if roll is not None:
             out["fused_rollout"] = roll
         if graph_sec is not None:

@@ -14,6 +14,8 @@ The record is ONE contiguous byte buffer laid out [obs int32 x N | reward float3
 done uint8 x N | pad]; the step kernel writes straight into its three views, so the gather
 needs no packing kernel and is a single collective of 9*N (+pad) bytes per rank.
 """
+import logging
+
 import torch
 
 
@@ -24,6 +26,37 @@ def shard_range(global_envs, world_size, rank):
     base, rem = divmod(int(global_envs), int(world_size))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+_log = logging.getLogger("gymwipe_amd.sharding")
+
+
+def pick_all_gather(dist, group=None):
+    """The asynchronous all-gather-into-one-tensor entry every gather object of this module uses, chosen ONCE (at
+    construction) and for good: `fn(out, inp) -> Work`.
+
+    On a real c10d process group that is the backend object's `_allgather_base` -- the collective
+    `all_gather_into_tensor` issues, minus ~5 us of argument checking per call (at a 6 us step every microsecond the
+    host spends here is a microsecond the GPU may run dry).  It is a private entry, so it is taken only if its
+    signature reads `(output, input, ...)`; otherwise -- and for the loop-back stand-ins the tests inject -- the public
+    call is bound instead, and the choice is logged once.  A collective is NEVER re-issued after an exception from the
+    backend call itself: a rank that enqueued two collectives against its peers' one would mismatch or hang."""
+    pg = group
+    if pg is None:
+        try:
+            pg = dist.distributed_c10d._get_default_group()
+        except Exception:
+            pg = getattr(getattr(dist, "group", None), "WORLD", None)
+    base = getattr(pg, "_allgather_base", None)
+    doc = getattr(base, "__doc__", None) or ""
+    if base is not None and "output: torch.Tensor, input: torch.Tensor" in doc:
+        return base, "ProcessGroup._allgather_base"
+    if base is not None:
+        _log.warning("gymwipe_amd.sharding: ProcessGroup._allgather_base has an unexpected signature; "
+                     "using torch.distributed.all_gather_into_tensor")
+    if group is not None:
+        return (lambda out, inp: dist.all_gather_into_tensor(out, inp, group=group, async_op=True)), "all_gather_into_tensor"
+    return (lambda out, inp: dist.all_gather_into_tensor(out, inp, async_op=True)), "all_gather_into_tensor"
 
 
 class StepRecord:
@@ -80,24 +113,35 @@ class PipelinedGather:
 
 
 class ObservationGather:
-    """All-gather of equally sized StepRecords over the default process group."""
+    """The end-of-step observation gather the north star names: all-gather of equally sized StepRecords over the
+    default process group (or `group`), once per env.step()."""
 
-    def __init__(self, record, world_size=None, dist_module=None):
+    def __init__(self, record, world_size=None, dist_module=None, group=None):
         if dist_module is None:                      # tests may inject a loop-back stand-in for the process group
             import torch.distributed as dist_module
         dist = self._dist = dist_module
         self.world = world_size if world_size is not None else dist.get_world_size()
         self.record = record
         self.out = torch.empty(self.world * record.nbytes, dtype=torch.uint8, device=record.buf.device)
+        self._gather, self.entry = pick_all_gather(dist, group)
+        self._buf = record.buf
 
     def __call__(self, async_op=False):
-        """Gather every rank's record.  Synchronous form: returns the [world, nbytes] byte tensor
-        (valid once the collective has completed on the current stream).  With async_op=True the
-        collective runs on the backend's own stream and the Work handle is returned: the caller may
-        launch the next env.step() right away and must wait() on the handle before this record's
-        buffer (or `out`) is written again."""
-        work = self._dist.all_gather_into_tensor(self.out, self.record.buf, async_op=async_op)
-        return work if async_op else self.out.view(self.world, self.record.nbytes)
+        """Gather every rank's record.  Synchronous form: returns the [world, nbytes] byte tensor, valid for work
+        enqueued afterwards on the current stream (on RCCL `wait()` makes the current STREAM wait for the collective;
+        the host does not block).  With async_op=True the collective runs on the backend's own stream and the Work
+        handle is returned: the caller may launch the next env.step() right away and must wait() on the handle before
+        this record's buffer (or `out`) is written again."""
+        work = self._gather(self.out, self._buf)
+        if async_op:
+            return work
+        work.wait()
+        return self.out.view(self.world, self.record.nbytes)
+
+    def step_done(self):
+        """The per-step call of a stepping loop: gather this step's record and order the current stream behind it, so
+        that whatever is launched next (the next env.step(), the agent's forward pass) sees every rank's feedback."""
+        self._gather(self.out, self._buf).wait()
 
     def unpack(self):
         """(obs[W*N], reward[W*N], done[W*N]) of the whole job, rank-major (== global env order
@@ -125,7 +169,7 @@ class ChunkedFeedbackGather:
     step kernel stores the byte along with its outputs, so a chunk costs no packing launch at all).
     """
 
-    def __init__(self, num_envs, device, pack, world_size=None, chunk=64, depth=2, dist_module=None):
+    def __init__(self, num_envs, device, pack, world_size=None, chunk=64, depth=2, dist_module=None, group=None):
         if dist_module is None:                      # tests may inject a loop-back stand-in for the process group
             import torch.distributed as dist_module
         dist = self._dist = dist_module
@@ -133,6 +177,7 @@ class ChunkedFeedbackGather:
         n, g = int(num_envs), int(chunk)
         self.num_envs, self.chunk, self.depth = n, g, depth
         self._pack = pack
+        self._gather, self.entry = pick_all_gather(dist, group)
         mk = lambda dt: [torch.zeros((g, n), dtype=dt, device=device) for _ in range(depth)]
         self.obs, self.reward, self.done = mk(torch.int32), mk(torch.float32), mk(torch.uint8)
         self.packed = mk(torch.uint8)
@@ -200,22 +245,8 @@ class ChunkedFeedbackGather:
         # full one on the links, not all of it
         cnt = steps * self.num_envs
         out = self.gathered[b].view(-1)[:self.world * cnt]
-        self.pending[b] = self._all_gather(out, self.packed[b].view(-1)[:cnt])
+        self.pending[b] = self._gather(out, self.packed[b].view(-1)[:cnt])
         return b
-
-    def _all_gather(self, out, inp):
-        """Asynchronous all-gather into one tensor.  On a real process group the call goes to the backend object directly
-        (ProcessGroup._allgather_base: the same collective all_gather_into_tensor issues, minus ~5 us of argument checking
-        per call -- at a 6 us step every microsecond the host spends here is a microsecond the GPU may run dry)."""
-        dist = self._dist
-        pg = getattr(getattr(dist, "group", None), "WORLD", None)
-        base = getattr(pg, "_allgather_base", None)
-        if base is not None:
-            try:
-                return base(out, inp)
-            except Exception:                          # an unexpected backend signature: the public call is always there
-                pass
-        return dist.all_gather_into_tensor(out, inp, async_op=True)
 
     def drain(self):
         """Flush a partly filled chunk and wait for every gather in flight."""

@@ -68,6 +68,36 @@ def test_bench_multi_gpu_code_path_runs_on_rccl_with_one_rank():
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-1000:]                  # ONE line on stdout although RCCL prints a banner to fd 1
     d = json.loads(lines[0])
-    assert d["config"]["obs_gather"] is True and "per 16 steps" in d["config"]["parallelism"]
-    assert "error" not in d["per_step_gather"], d["per_step_gather"]
-    assert d["per_step_gather"]["bytes_per_rank_per_step"] == 9 * 8192 and d["value"] > 1e6
+    assert d["config"]["obs_gather"] == "per-step" and "after EVERY env.step()" in d["config"]["parallelism"]
+    g = d["gather_forms"]
+    for form, late in (("no_gather", None), ("pipelined_gather", 1), ("chunked_gather", 16)):
+        assert "error" not in g[form], g[form]
+        assert g[form]["observations_late_by_steps"] == late and g[form]["env_steps_per_s"] > 1e6
+    assert g["pipelined_gather"]["bytes_per_rank_per_step"] == 9 * 8192 and g["chunked_gather"]["bytes_per_rank_per_step"] == 8192
+    assert d["value"] > 1e6 and d["value"] <= g["no_gather"]["env_steps_per_s"] * 1.5
+    r = d["ranks"]
+    assert r["world_size"] == 1 and r["backend"] == "nccl" and len(r["devices"]) == 1 and r["devices"][0] and r["rccl_version"]
+    assert "without the per-step gather" in d["roofline"]["how"].lower()
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher: the parent starts two fresh rank processes before touching HIP, relays
+    rank 0's one line and exits 0.  Two RCCL ranks cannot share the one GPU of this box, so the collectives run on gloo
+    (GW_BENCH_BACKEND=gloo: the rehearsal mode) -- launcher, rendezvous, sharded action stream, per-step gather protocol,
+    max-over-ranks timing and the `ranks` evidence are the code the driver's N-GPU command runs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["GW_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--envs", "8192", "--repeats", "10"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * 8192 and d["config"]["obs_gather"] == "per-step"
+    assert "cpu_baseline" not in d and d["scaling"] == "weak" and d["value"] > 1e5
+    r = d["ranks"]
+    assert r["world_size"] == 2 and r["backend"] == "gloo" and len(r["devices"]) == 2 and "launch_ranks" in r["launcher"]
+    assert sorted(e["rank"] for e in r["per_rank"]) == [0, 1] and len({e["pid"] for e in r["per_rank"]}) == 2
+    for form in ("no_gather", "pipelined_gather", "chunked_gather"):
+        assert "error" not in d["gather_forms"][form], d["gather_forms"][form]

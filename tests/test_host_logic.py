@@ -5,7 +5,10 @@ an env without a HIP device, and its host-only self-tests must pass.
 """
 import ctypes as C
 import os
+import json
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -325,3 +328,62 @@ def test_both_library_builds_export_the_c_abi_and_the_loader_defaults_to_the_por
     import torch
     if not torch.cuda.is_available() and not os.environ.get("GW_LIB"):
         assert nat._pick_library() == nat.LIB_PATH
+
+
+# ---- bench.py's own rank launcher (plain `python bench.py --gpus N`): spawn / relay / failure logic, no GPU involved ----
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gw_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                     # top level imports neither torch nor the package
+    return mod
+
+
+def test_bench_launcher_starts_n_ranks_and_relays_rank_zero(capfd):
+    bench = _bench_module()
+    child = ("import os, sys, json; r = int(os.environ['RANK']); "
+             "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'; "
+             "int(os.environ['MASTER_PORT']); "
+             "print(json.dumps({'rank': r, 'port': os.environ['MASTER_PORT']})); sys.stderr.write('err%d\\n' % r)")
+    rc = bench.launch_ranks(3, [sys.executable, "-c", child], timeout=60)
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["rank"] == 0          # only rank 0's stdout reaches stdout
+    assert '"rank": 1' in err and '"rank": 2' in err                      # the other ranks' stdout went to stderr
+    assert "err0" in err and "err2" in err
+
+
+def test_bench_launcher_fails_the_job_when_one_rank_fails_and_stops_the_rest():
+    import time as _time
+    bench = _bench_module()
+    child = ("import os, sys, time; r = int(os.environ['RANK']);\n"
+             "if r == 1: sys.exit(7)\n"
+             "time.sleep(600)")
+    t0 = _time.monotonic()
+    rc = bench.launch_ranks(2, [sys.executable, "-c", child], timeout=120, grace=0.5)
+    assert rc == 7 and _time.monotonic() - t0 < 30                        # rank 0 (sleeping) was terminated, not waited for
+
+
+def test_bench_launcher_times_out():
+    bench = _bench_module()
+    rc = bench.launch_ranks(2, [sys.executable, "-c", "import time; time.sleep(600)"], timeout=1.0, grace=0.5)
+    assert rc == 124
+
+
+def test_bench_self_launch_happens_before_torch_is_imported():
+    """`bench.py --gpus 2` without WORLD_SIZE must reach launch_ranks with neither torch nor the package imported in the
+    parent (a parent that had initialised HIP could not safely start GPU children)."""
+    code = ("import sys, runpy\n"
+            "sys.argv = ['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0']\n"
+            "import importlib.util\n"
+            "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "def fake(n, argv, timeout=None, env=None, grace=10.0):\n"
+            "    assert 'torch' not in sys.modules and 'gymwipe_amd' not in sys.modules, 'imported before the launch'\n"
+            "    assert n == 2 and argv[0] == sys.executable and argv[1].endswith('bench.py') and argv[2:] == sys.argv[1:]\n"
+            "    return 5\n"
+            "b.launch_ranks = fake\n"
+            "b.main()\n" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert out.returncode == 5, (out.stdout, out.stderr[-2000:])

@@ -710,9 +710,9 @@ def main():
                        "actions": "counter-based generator, seed %d (gymwipe_amd/actions.py), identical for the CPU baseline" % SEED,
                        "obs_gather": ("per-step" if gathering else False) if multi else False,
                        "parallelism": ("independent env shards, one process per GPU, no data-path collective; only exchange: the "
-                                       "end-of-step observation gather -- one RCCL all-gather of each rank's %d-byte (obs, reward, done) "
+                                       "end-of-step observation gather -- one %s all-gather of each rank's %d-byte (obs, reward, done) "
                                        "record after EVERY env.step(), on the step's stream, so that step k+1 is launched behind the "
-                                       "gather of step k (entry: %s)" % (rec.nbytes, gather_entry)) if gathering
+                                       "gather of step k (entry: %s)" % ("RCCL" if backend == "nccl" else backend, rec.nbytes, gather_entry)) if gathering
                                       else "independent env shards, one process per GPU, no exchange",
                        "launches_per_step": 1, "stream_ms_per_step": kern_avg_s * 1e3},
             "roofline": roof,

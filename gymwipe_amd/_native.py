@@ -17,7 +17,7 @@ QUEUE_CAP = 100
 MAX_NSTATES = 16
 
 OK, EINVAL, ENODEVICE, EHIP, ENOMEM, EUNSUPPORTED, EFIELD = 0, -1, -2, -3, -4, -5, -6
-FLAG_CARRY, FLAG_REFEXC, FLAG_TIE, FLAG_BADACT = 1, 2, 4, 8
+FLAG_CARRY, FLAG_REFEXC, FLAG_TIE, FLAG_BADACT, FLAG_INTERNAL = 1, 2, 4, 8, 16
 CFG_PER_ENV_STATS = 1
 CFG_EXPLICIT_QUEUE = 2
 CFG_NO_COUNTER_TRAFFIC = 4

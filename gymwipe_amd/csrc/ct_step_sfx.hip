@@ -182,13 +182,13 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     //      arrived meanwhile, and no wait for them stands between the wave's start and its first vector loads --------------------------------
     StepMathT<FAST, NOLIM> m(c);
     double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
-    double coded_factor = c.coded_factor, cls_limit = c.cls_limit, inv_interval = c.inv_interval;
+    double coded_factor = c.coded_factor, cls_limit = c.cls_limit, inv_interval_lo = c.inv_interval_lo, inv_slot_lo = c.inv_slot_lo;
     int pv = c.payload_value, cbound = c.counter_bound, max_duration = c.max_duration, dfactor = c.duration_factor;
     int mh = c.mac_hdr, base_b = c.mac_hdr + c.net_hdr, idem_i = c.idem_states, fast_ticks = c.fast_ticks;
     __builtin_amdgcn_sched_barrier(0);
     PIN_V(m.slot); PIN_V(m.inv_slot); PIN_V(m.fmod_limit); PIN_V(m.dr); PIN_V(m.rcp_dr); PIN_V(m.max_ber);
     if (!FAST) { PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide); }
-    PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit); PIN_V(inv_interval);
+    PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit); PIN_V(inv_interval_lo); PIN_V(inv_slot_lo);
     PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i); PIN_S(fast_ticks);
     if (FEEDBACK) { PIN_S(obs); PIN_S(reward); PIN_S(done); PIN_S(fb); }   // the output pointers too (the kernel's only arguments that are not preloaded)
     __builtin_amdgcn_sched_barrier(0);
@@ -338,13 +338,18 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             };
 
             // the same in one jump (gw_fastmath.h: a floor division corrected by the exact FMA residual; exact, validated at
-            // gw_create) wherever its preconditions hold, else by the loop above.  A data packet of the first steps after a
-            // reset lasts 2-4 ms = 2-4 ticks: the loop then often needs a second pass, the jump never does (-2 % per step).
+            // gw_create).  The jump's time-independent preconditions are established ONCE for the step (gw_tick_span_ok over
+            // [wake, t_end]: one binade, constant increment, exact differences), so that a call is a dozen instructions; a lane
+            // whose step does not qualify (the first 62 ms of an env, a binade end within reach, a rounding-tie interval) counts
+            // with the running-sum loop above.  A data packet of the first steps after a reset lasts 2-4 ms = 2-4 ticks.
+            double delta = 0.0;
+            const bool span_ok = (FAST || fast_ticks) && gw_tick_span_ok(wake, t_end, interval, &delta);
             auto ticks_upto = [&](double t, bool inclusive) {
                 uint32_t nj = 0;
                 double wj = wake;
-                bool tiej = false;
-                if ((FAST || fast_ticks) && gw_tick_jump(wake, t, interval, inv_interval, inclusive, &nj, &wj, &tiej)) {
+                bool tiej = false, sane = false;
+                gw_tick_jump_lo(wake, t, delta, inv_interval_lo, inclusive, &nj, &wj, &tiej, &sane);
+                if (span_ok && sane) {
                     wake = wj;
                     tau += nj;
                     if (tiej) fl |= GW_FLAG_TIE;
@@ -359,7 +364,81 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
                 const double stopw = t_r + total;                        // :401 (== timeout time :406)
                 double cur = t_r;
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
-                ticks_to(cur, false);                                    // (0 or 1 tick here: the loop's single pass is cheaper than the jump)
+                ticks_upto(cur, false);
+                // ---- the window loop, straight-line form (MI355X: one wave per SIMD issues one instruction per 4-8 cycles
+                //      whatever it is, and the wave lasts as long as its busiest lane's 8-9 packets; in-kernel stamps put the
+                //      general loop below at 945 + 974 cycles per packet of that lane, exec-mask bookkeeping around its
+                //      per-packet decisions included).  A lane takes the straight line when every one of those decisions is known
+                //      in advance for the whole step:
+                //        * tick jumps apply (span_ok) and the exact fast forms of fmod and division hold up to t_end;
+                //        * the RRM's decode outcome is certain by class, its noise state idempotent;
+                //        * t_r >= 2 (t_end - t_r): every packet's stop - t_s is exact (Sterbenz), so the completion event
+                //          t_s + (stop - t_s) IS stop -- no select, no `not t.completed` case (GW_FLAG_REFEXC);
+                //      and while the queue neither runs empty nor needs the breakpoint ring (> 2 resets inside its span).  The
+                //      loop is software-pipelined -- an iteration transmits the packet whose fit was established by the
+                //      previous one, then sizes the next head -- has ONE exit condition and no branch inside; everything it
+                //      does is unconditional, because a lane that leaves never runs another iteration.  GW_FLAG_CARRY can only
+                //      be raised by a window's last packet and is tested once behind the loop; the tick jump's self-check is
+                //      accumulated and raises GW_FLAG_INTERNAL (never expected: gw_fastmath.h).
+                bool more = true;
+                const double span = t_end - t_r;
+                const bool straight = span_ok && mult_d != 0u && idem && cls_valid && cls_x1 != (uint32_t)GW_CLS_COMPUTE &&
+                                      (FAST || (m.fast_fmod && m.fast_div)) && (NOLIM || t_end < m.fmod_limit) &&
+                                      t_r >= span + span;
+                uint32_t pops = 0;
+                if (straight && len_d != 0u) {                            // (an empty queue waits for a tick: general loop)
+                    auto head = [&](uint32_t len, uint32_t tk_now, bool& deep) {
+                        const uint32_t age = __umul24(len + mult_d - 1u, inv16_d) >> 16;      // gw_ceil_div
+                        const uint32_t ht = tk_now - age;                 // tick of the head packet
+                        const bool older = ht < bpc.t0;
+                        deep = older && ht < bpp.t0;                      // > 2 resets inside the queue's span
+                        return base_bytes + gw_min_u32((older ? bpp.c0 : bpc.c0) + (ht - (older ? bpp.t0 : bpc.t0)), bound);
+                    };
+                    // (loop-carried VALUES only: a bool that lives across a divergent loop is a lane mask the compiler
+                    //  re-merges with three scalar instructions per iteration)
+                    bool deep = false;
+                    uint32_t chk = 0;
+                    uint32_t s = head(len_d, tau, deep);
+                    bool go = !deep && (stopw - cur) > gw_fast_div((double)(s * 8u), m.dr, m.rcp_dr);   // :418-420
+                    while (go) {
+                        // ---- transmit the head packet: pop (:425), slot alignment (simple_stack.py:204), durations
+                        //      (physical.py:244-279); the completion event fires at stop (see above)
+                        const double pd = gw_fast_div((double)(((int)s - mh) * 8), m.dr, m.rcp_dr);
+                        const double t_s = cur + (m.slot - gw_fast_fmod_lo(cur, m.slot, inv_slot_lo));
+                        const double t_e = t_s + (hd + pd);
+                        // ---- counter ticks up to and including t_e (older events than the MAC's resume)
+                        uint32_t nj = 0;
+                        double wj = wake;
+                        bool tiej = false, sane = false;
+                        gw_tick_jump_lo(wake, t_e, delta, inv_interval_lo, true, &nj, &wj, &tiej, &sane);
+                        chk |= (sane ? 0u : (uint32_t)GW_FLAG_INTERNAL) | (tiej ? (uint32_t)GW_FLAG_TIE : 0u);
+                        len_d = gw_min_u32(len_d - 1u + __umul24(nj, mult_d), (uint32_t)GW_QUEUE_CAP);
+                        tau += nj;
+                        wake = wj;
+                        cur = t_e;
+                        pops++;
+                        // ---- the next head, and whether the loop goes on: window still open (else its timeout has been
+                        //      processed), a packet there, no breakpoint-ring lookup, and it fits (messages.py:67-75, :418-420)
+                        bool deep_n = false;
+                        s = head(len_d, tau, deep_n);
+                        go = cur < stopw && len_d != 0u && !deep_n && (stopw - cur) > gw_fast_div((double)(s * 8u), m.dr, m.rcp_dr);
+                    }
+                    // the general loop takes over where the window is still open and the straight line ended on something it
+                    // does not model (queue ran empty, breakpoint ring)
+                    (void)head(len_d, tau, deep);
+                    more = cur < stopw && (len_d == 0u || deep);
+                    fl |= chk | ((pops && !(cur < t_end)) ? (uint32_t)GW_FLAG_CARRY : 0u);
+                }
+                if (pops) {                                               // devices.py:163-168, counter_traffic.py:75-80
+                    const bool okx = cls_x1 == (uint32_t)GW_CLS_OK;
+                    k.pop += pops;
+                    n_data += (int)pops;
+                    s_r = s_r1;
+                    k.deliv += okx ? pops : 0u;
+                    rvm |= okx ? (1u << d) : 0u;
+                    dn = (okx && pv == cbound) ? 1u : dn;
+                }
+                if (more)
                 for (;;) {
                     if (len_d == 0) {                                     // :409-416
                         // (a silent sender, mult 0, never signals packet-added: the MAC waits for the timeout)

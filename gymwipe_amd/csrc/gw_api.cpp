@@ -158,6 +158,8 @@ void set_fast_paths(const gw_config& cfg_ref, const GwHostTables& tab, GwDevCons
     k.cls_limit = (no_fast || getenv("GW_NO_CLASSES")) ? 0.0 : 1.0e6;
     k.fast_decide = (!no_fast && cfg->max_ber == 0.25 && tab.coded_factor * 8.0 == floor(tab.coded_factor * 8.0)) ? 1 : 0;
     k.inv_interval = 1.0 / cfg->counter_interval;
+    k.inv_slot_lo = gw_inv_lo(cfg->slot);
+    k.inv_interval_lo = gw_inv_c_lo(cfg->counter_interval);
     {
         // If tick number j after `wake` equals t exactly, then t - wake = j*c + E with |E| <= j * ulp(t)/2 (one rounding per
         // addition of the running sum), so (t - wake)/c is within j*ulp(t)/(2c) of j.  j <= jmax ticks per step, t < 2^21 s

@@ -36,6 +36,7 @@ struct GwDevConst {
     int32_t dest[GW_MAX_DEVICES];
     double  ten_log_br, twenty_log_f, tx_power_dbm;   // 10*log10(bit_rate), 20*log10(frequency) (host glibc), tx power: live-PHY kernel
     uint32_t inv20[GW_MAX_DEVICES];     // ceil(2^20 / mult[i]): p / mult for p * mult < 2^20 (generic kernel's append index -> tick)
+    double  inv_slot_lo, inv_interval_lo;   // one-sided reciprocals of gw_fast_fmod_lo / gw_tick_jump_lo (gw_fastmath.h)
 };
 
 struct GwBp { uint32_t t0, c0; };        // counting restarts at tick t0 with counter value c0

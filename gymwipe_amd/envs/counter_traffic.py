@@ -512,6 +512,8 @@ class VecCounterTrafficEnv(BaseEnv):
         st["ties"] = bool(fl & nat.FLAG_TIE)
         if fl & nat.FLAG_BADACT:
             raise AssertionError("%d env-step(s) had an action outside the action space" % st["bad_actions"])
+        if fl & nat.FLAG_INTERNAL:
+            raise RuntimeError("a kernel self-check failed in some env (GW_FLAG_INTERNAL): state invalid, please report")
         if fl & (nat.FLAG_CARRY | nat.FLAG_REFEXC):
             raise RuntimeError("step horizon not closed in some env (flags 0x%x)" % fl)
         if strict and st["ties"]:

@@ -74,6 +74,7 @@ extern "C" {
 #define GW_FLAG_REFEXC   2u   /* the reference would raise here (simple_stack.py:166 KeyError) */
 #define GW_FLAG_TIE      4u   /* an exact f64 time tie was resolved by the insertion-order rule */
 #define GW_FLAG_BADACT   8u   /* action outside the action space: env left untouched this step */
+#define GW_FLAG_INTERNAL 16u  /* a kernel self-check of an exact fast path failed (never expected; the env's state is invalid) */
 
 typedef struct gw_config {
     int32_t abi_version;                    /* GW_ABI_VERSION */

@@ -20,6 +20,8 @@ names = ["0 issue table+state loads, write LDS", "1 barrier", "2 state landed (t
          "4 announcement tx_times", "5 announcement decode, t_end", "6 window loop", "7 tail ticks_to(t_end)",
          "8 other senders + pack", "9 qb store", "10 feedback + stores", "11 counters store"]
 rows = []
+pops_rows = []
+prev_pop = env.get_state("n_popped").astype(np.int64)
 for k in range(3 * (W + K)):
     if k % (W + K) == 0:
         env.reset()
@@ -32,6 +34,10 @@ for k in range(3 * (W + K)):
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         w = out[: N // 64].astype(np.int64)
         rows.append(np.diff(w[:, :13], axis=1))
+    cur_pop = env.get_state("n_popped").astype(np.int64)
+    if k % (W + K) >= W:
+        pops_rows.append((cur_pop - prev_pop).reshape(-1, 64).max(axis=1))      # data packets of the wave's busiest lane
+    prev_pop = cur_pop
 d = np.concatenate(rows)
 print("cycles per wave (s_memtime ticks; each stamp itself costs ~100), median / p90 / mean / max over %d waves x %d launches (steps %d..%d after a reset)" % (N // 64, len(rows), W, W + K - 1))
 for i, n in enumerate(names):
@@ -40,4 +46,13 @@ tot = d.sum(axis=1)
 print("  %-48s %8.0f %8.0f %8.0f %8.0f" % ("total in-kernel", np.median(tot), np.percentile(tot, 90), tot.mean(), tot.max()))
 per_launch_max = np.array([r.sum(axis=1).max() for r in rows])
 print("  slowest wave of a launch: mean %.0f  (the launch lasts at least this long)" % per_launch_max.mean())
+# window-loop cycles against the packet count of the wave's busiest lane: slope = cycles per packet iteration
+mp = np.concatenate(pops_rows)
+loop = d[:, 6]
+A = np.stack([mp, np.ones_like(mp)], axis=1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(A, loop.astype(np.float64), rcond=None)
+print("  window loop ~= %.0f + %.0f x (packets of the busiest lane); busiest lane: median %d, p90 %d, max %d packets" % (coef[1], coef[0], np.median(mp), np.percentile(mp, 90), mp.max()))
+for q in sorted(set(mp.tolist())):
+    sel = loop[mp == q]
+    print("    %2d packets: %6d waves, loop median %6.0f" % (q, sel.size, np.median(sel)))
 # (wave start/end offsets across the launch are not reported: s_memtime counters of different CUs are not comparable)

@@ -235,12 +235,12 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     uint32_t tau = tk.x;
     const uint32_t nbp = tk.y;
     GwBp bpc, bpp;
-    bpc.t0 = tk.z; bpc.c0 = tk.w;
-    bpp.t0 = ip.x; bpp.c0 = ip.y;
+    bpc.t0 = ip.x; bpc.c0 = ip.y;                // (record layout: ct_step_sfx.hip)
+    bpp.t0 = ip.z; bpp.c0 = ip.w;
     const GwBp* hist = st.bph + ((size_t)e << 7);
-    uint32_t rvm = ip.z;
-    int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
-    uint32_t dn = ip.w >> 31;
+    uint32_t rvm = tk.z;
+    int32_t last_abs = (int32_t)(tk.w & 0x7fffffffu);
+    uint32_t dn = tk.w >> 31;
 
     constexpr bool FAST = MODE >= 1, NOLIM = MODE == 2;
     const StepMathT<FAST, NOLIM> m(c);
@@ -521,8 +521,7 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
         }
     }
     st_(st.tw, o16, make_double2(now, wake));
-    st_(st.tk, o16, tau);
-    st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
+    st_(st.tk, o16, make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31)));
     publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl, (uint32_t)K);
 }
 

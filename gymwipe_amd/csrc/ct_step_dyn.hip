@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
     const uint4 tk = ld<uint4>(st.tk, o16);
 
     const StepMath m(c);
-    uint32_t rvm = ip.z;
-    int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
-    uint32_t dn = ip.w >> 31;
+    uint32_t rvm = tk.z;                          // (record layout: ct_step_sfx.hip)
+    int32_t last_abs = (int32_t)(tk.w & 0x7fffffffu);
+    uint32_t dn = tk.w >> 31;
     uint32_t fl = 0, k_bad = 0;
     Tally k = {0, 0, 0, 0, 0};
     const int pv = c.payload_value;
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         double wake = tw.y;
         const uint32_t tau0 = tk.x, nbp = tk.y;
         GwBp bpc, bpp;
-        bpc.t0 = tk.z; bpc.c0 = tk.w;
-        bpp.t0 = ip.x; bpp.c0 = ip.y;
+        bpc.t0 = ip.x; bpc.c0 = ip.y;
+        bpp.t0 = ip.z; bpp.c0 = ip.w;
         const GwBp* hist = st.bph + ((size_t)e << 7);
 
         const int slots = du * c.duration_factor;                         // counter_traffic.py:149
@@ -220,8 +220,7 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         done[e] = (uint8_t)dn;
 
         st_(st.tw, o16, make_double2(t_end, wake));
-        st_(st.tk, o16, tau);
-        st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
+        st_(st.tk, o16, make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31)));
     }
     publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl, 1u);
 }

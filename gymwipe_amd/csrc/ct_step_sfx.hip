@@ -6,8 +6,10 @@
 // it loads four 16-byte records per env, walks the event horizon of the step in registers, and stores
 // the records back.  Per-env HBM layout (all offsets 32-bit):
 //     tw[e] = {now, next tick}                      2 x f64
-//     tk[e] = {tau, nbp, newest breakpoint}         4 x u32
-//     ip[e] = {2nd newest breakpoint, rvmask, last_abs | done<<31}
+//     tk[e] = {tau, nbp, rvmask, last_abs | done<<31}   4 x u32: what a step changes, stored WHOLE (a 4-byte and an 8-byte
+//                                                       store into two records went out as partial lines under write-through:
+//                                                       1.46x the bytes the encoding needs, profiles/r2_final_sq)
+//     ip[e] = {newest breakpoint, 2nd newest breakpoint}   written by reset / init only
 //     qb[e] = bytes: len[0..D), rx-power state[0..D], pad to 16
 //
 // Step walk, reference file:line:
@@ -209,13 +211,13 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     auto t_h2 = [&](uint32_t j, uint32_t dd, uint32_t ss) { return (uint32_t)g_h2[(ss * DD + j) * DD + dd]; };
 
     if (live) {
-        uint32_t rvm = ip.z;
+        uint32_t rvm = tk.z;
 #ifdef GW_STAMPS
         asm volatile("" : "+v"(rvm));         // diagnostic build: touch ip so that the stamp below sits after the state loads have landed
 #endif
         STAMP(3);
-        int32_t last_abs = (int32_t)(ip.w & 0x7fffffffu);
-        uint32_t dn = ip.w >> 31;
+        int32_t last_abs = (int32_t)(tk.w & 0x7fffffffu);
+        uint32_t dn = tk.w >> 31;
         uint32_t fl = 0;
 
         if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)max_duration) {
@@ -267,8 +269,8 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             double wake = tw.y;
             const uint32_t tau0 = tk.x, nbp = tk.y;
             GwBp bpc, bpp;
-            bpc.t0 = tk.z; bpc.c0 = tk.w;
-            bpp.t0 = ip.x; bpp.c0 = ip.y;
+            bpc.t0 = ip.x; bpc.c0 = ip.y;
+            bpp.t0 = ip.z; bpp.c0 = ip.w;
             const GwBp* hist = st.bph + ((size_t)e << 7);
             // what the addressed sender / the RRM become after hearing the RRM / sender d once
             const uint32_t s_d = t_h1((uint32_t)d, s_d_old);
@@ -556,8 +558,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
             now_out = t_end;
 
             st_(st.tw, o16, make_double2(t_end, wake));
-            st_(st.tk, o16, tau);                                         // only the tick counter changes
-            st_(st.ip, o16 + 8u, make_uint2(rvm, (uint32_t)last_abs | (dn << 31)));
+            st_(st.tk, o16, make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31)));   // whole records only
         }
         STAMP(11);
         // ---- per-env event counters (popped, delivered, bad, flags: the rest is derived from the state) ----
@@ -750,8 +751,8 @@ __global__ void ct_init_sfx_kernel(GwState st)
     if (e >= (uint32_t)st.N) return;
     const uint32_t o16 = e << 4;
     st_(st.tw, o16, make_double2(st.cst->start_time, st.cst->start_time));
-    st_(st.tk, o16, make_uint4(0u, 1u, 0u, 1u));
-    st_(st.ip, o16, make_uint4(0u, 1u, 0u, 0u));
+    st_(st.tk, o16, make_uint4(0u, 1u, 0u, 0u));          // tau 0, one breakpoint, nothing received
+    st_(st.ip, o16, make_uint4(0u, 1u, 0u, 0u));          // newest breakpoint (tick 0, value 1)
     for (int b = 0; b < st.RB; ++b) st.qb[e * (uint32_t)st.RB + b] = 0;
     GwBp b0; b0.t0 = 0u; b0.c0 = 1u;
     st.bph[(size_t)e << 7] = b0;
@@ -769,22 +770,23 @@ __global__ void ct_reset_sfx_kernel(GwState st, const uint8_t* __restrict__ mask
     uint32_t rvm;
     if (!mask || mask[e]) {
         uint4 tk = ld<uint4>(st.tk, o16);
-        GwBp cur; cur.t0 = tk.z; cur.c0 = tk.w;
-        if (cur.t0 == tk.x) {                      // no tick since the newest breakpoint: overwrite it
-            cur.c0 = 0u;
+        uint4 bp = ld<uint4>(st.ip, o16);          // {newest (t0, c0), second newest (t0, c0)}
+        GwBp cur; cur.t0 = bp.x; cur.c0 = 0u;
+        if (bp.x == tk.x) {                        // no tick since the newest breakpoint: overwrite it
             st.bph[((size_t)e << 7) + ((tk.y - 1u) & GW_RING_MASK)] = cur;
-            tk.w = 0u;
-            st_(st.ip, o16 + 8u, make_uint2(0u, 0u));
+            bp.y = 0u;
         } else {
-            st_(st.ip, o16, make_uint4(cur.t0, cur.c0, 0u, 0u));   // old newest becomes second newest
-            cur.t0 = tk.x; cur.c0 = 0u;
+            bp.z = bp.x; bp.w = bp.y;              // old newest becomes second newest
+            cur.t0 = tk.x;
             st.bph[((size_t)e << 7) + (tk.y & GW_RING_MASK)] = cur;
-            tk.y += 1u; tk.z = cur.t0; tk.w = 0u;
+            tk.y += 1u; bp.x = cur.t0; bp.y = 0u;
         }
+        tk.z = 0u; tk.w = 0u;                      // interpreter.reset(): receivedValues, lastAbs, done
         st_(st.tk, o16, tk);
+        st_(st.ip, o16, bp);
         rvm = 0u;
     } else {
-        rvm = ld<uint4>(st.ip, o16).z;
+        rvm = ld<uint4>(st.tk, o16).z;
     }
     if (obs) obs[e] = st.cst->payload_value * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u)) + st.cst->counter_bound;
 }
@@ -796,7 +798,7 @@ __global__ void ct_received_sfx_kernel(GwState st, int32_t* __restrict__ out)
     if (idx >= st.N * D) return;
     const uint32_t e = (uint32_t)(idx / D);
     const int i = (int)(idx - (int64_t)e * D);
-    const uint32_t rvm = ld<uint4>(st.ip, e << 4).z;
+    const uint32_t rvm = ld<uint4>(st.tk, e << 4).z;
     out[idx] = ((rvm >> i) & 1u) ? st.cst->payload_value : 0;
 }
 

@@ -1010,20 +1010,20 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         if (!strcmp(field, "counter")) {             // sender.counter == value of the next tick
             NEED(N * D, uint32_t); uint32_t* o = (uint32_t*)dst;
             for (int64_t e = 0; e < N; ++e) {
-                const uint32_t v = gw_min_u32(tk[e * 4 + 3] + (tk[e * 4] - tk[e * 4 + 2]), bound);
+                const uint32_t v = gw_min_u32(ip[e * 4 + 1] + (tk[e * 4] - ip[e * 4]), bound);   // newest breakpoint: ip {t0, c0}
                 for (int i = 0; i < D; ++i) o[e * D + i] = v;
             }
             return GW_OK;
         }
-        if (!strcmp(field, "last_abs")) { NEED(N, int32_t); int32_t* o = (int32_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = (int32_t)(ip[e * 4 + 3] & 0x7fffffffu); return GW_OK; }
+        if (!strcmp(field, "last_abs")) { NEED(N, int32_t); int32_t* o = (int32_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = (int32_t)(tk[e * 4 + 3] & 0x7fffffffu); return GW_OK; }
         if (!strcmp(field, "latest_diff")) {
             NEED(N, int32_t); int32_t* o = (int32_t*)dst;
-            for (int64_t e = 0; e < N; ++e) { const uint32_t m = ip[e * 4 + 2]; o[e] = pv * ((int)(m & 1u) - (int)((m >> 1) & 1u)); }
+            for (int64_t e = 0; e < N; ++e) { const uint32_t m = tk[e * 4 + 2]; o[e] = pv * ((int)(m & 1u) - (int)((m >> 1) & 1u)); }
             return GW_OK;
         }
         if (!strcmp(field, "received")) {
             NEED(N * D, int32_t); int32_t* o = (int32_t*)dst;
-            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ((ip[e * 4 + 2] >> i) & 1u) ? pv : 0;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ((tk[e * 4 + 2] >> i) & 1u) ? pv : 0;
             return GW_OK;
         }
         if (!strcmp(field, "qlen")) {
@@ -1060,8 +1060,8 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
             const uint32_t base = (uint32_t)(env->cfg.mac_header_bytes + env->cfg.net_header_bytes);
             for (int64_t e = 0; e < N; ++e) {
                 GwBp cur, prev;
-                cur.t0 = tk[e * 4 + 2]; cur.c0 = tk[e * 4 + 3];
-                prev.t0 = ip[e * 4]; prev.c0 = ip[e * 4 + 1];
+                cur.t0 = ip[e * 4]; cur.c0 = ip[e * 4 + 1];
+                prev.t0 = ip[e * 4 + 2]; prev.c0 = ip[e * 4 + 3];
                 for (int i = 0; i < D; ++i)
                     expand_sfx(bound, base, (uint32_t)env->cfg.mult[i], qb[(size_t)e * RB + i], tk[e * 4], cur, prev,
                                tk[e * 4 + 1], &hist[(size_t)e * GW_RING_PHYS], o + ((size_t)e * D + i) * GW_QUEUE_CAP);

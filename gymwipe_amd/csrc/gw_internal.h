@@ -57,8 +57,8 @@ struct GwState {
     uint64_t* runs;       // [N][D][GW_RING_PHYS]  the runs in between (touched only when a run is created or used up)
     //  suffix (default): see gw_queue.h.  Packed so that one env costs four 16-byte loads:
     double*   tw;         // [N][2]     {now, next counter tick}
-    uint32_t* tk;         // [N][4]     {tau = ticks so far, nbp = breakpoints so far, newest breakpoint (t0, c0)}
-    uint32_t* ip;         // [N][4]     {second newest breakpoint (t0, c0), rvmask, last_abs | done << 31}
+    uint32_t* tk;         // [N][4]     {tau = ticks so far, nbp = breakpoints so far, rvmask, last_abs | done << 31}: stored whole per step
+    uint32_t* ip;         // [N][4]     {newest breakpoint (t0, c0), second newest breakpoint (t0, c0)}: written by reset / init only
     uint8_t*  qb;         // [N][RB]    bytes: queue length of sender 0..D-1, rx-power state of radio 0..D, pad
     GwBp*     bph;        // [N][GW_RING_PHYS]  ring of all breakpoints, entry j at [j & 127] (read only after >2 resets/100 ticks)
     int32_t   RB;         //            bytes per qb record: 16 * ceil((2*D + 1) / 16)

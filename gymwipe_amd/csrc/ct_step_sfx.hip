@@ -159,7 +159,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     const uint32_t oq = e * RB, oql = el * RB;
     int d = device[el];
     int du = duration[el];
-    const uint4 ip = ld<uint4>(st.ip, o16l);
+    uint4 ip = ld<uint4>(st.ip, o16l);
     const double2 tw = ld<double2>(st.tw, o16l);
     const uint4 tk = ld<uint4>(st.tk, o16l);
     uint4 qw[NWC];
@@ -188,9 +188,12 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     int pv = c.payload_value, cbound = c.counter_bound, max_duration = c.max_duration, dfactor = c.duration_factor;
     int mh = c.mac_hdr, base_b = c.mac_hdr + c.net_hdr, idem_i = c.idem_states, fast_ticks = c.fast_ticks;
     __builtin_amdgcn_sched_barrier(0);
-    PIN_V(m.slot); PIN_V(m.inv_slot); PIN_V(m.fmod_limit); PIN_V(m.dr); PIN_V(m.rcp_dr); PIN_V(m.max_ber);
+    // (as SCALAR registers: a vector instruction takes one scalar operand, which is all these expressions need; pinned as
+    //  vector registers each double cost two v_mov at the top of every wave -- 30 instructions of a wave that issues one per
+    //  4-8 cycles)
+    PIN_S(m.slot); PIN_S(m.inv_slot); PIN_S(m.fmod_limit); PIN_S(m.dr); PIN_S(m.rcp_dr); PIN_S(m.max_ber);
     if (!FAST) { PIN_S(m.fast_fmod); PIN_S(m.fast_div); PIN_S(m.fast_decide); }
-    PIN_V(slot); PIN_V(br); PIN_V(hd); PIN_V(hdr_bits); PIN_V(interval); PIN_V(coded_factor); PIN_V(cls_limit); PIN_V(inv_interval_lo); PIN_V(inv_slot_lo);
+    PIN_S(slot); PIN_S(br); PIN_S(hd); PIN_S(hdr_bits); PIN_S(interval); PIN_S(coded_factor); PIN_S(cls_limit); PIN_S(inv_interval_lo); PIN_S(inv_slot_lo);
     PIN_S(pv); PIN_S(cbound); PIN_S(max_duration); PIN_S(dfactor); PIN_S(mh); PIN_S(base_b); PIN_S(idem_i); PIN_S(fast_ticks);
     if (FEEDBACK) { PIN_S(obs); PIN_S(reward); PIN_S(done); PIN_S(fb); }   // the output pointers too (the kernel's only arguments that are not preloaded)
     __builtin_amdgcn_sched_barrier(0);
@@ -198,6 +201,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     // (the action is used unconditionally here, so that its loads stay at the top with the others: with every use inside
     //  `if (live)` the compiler sank them into that block, behind the waits above)
     PIN_V(d); PIN_V(du);
+    PIN_V(ip.x); PIN_V(ip.y); PIN_V(ip.z); PIN_V(ip.w);   // (the breakpoints are first used in the window: keep their load up here too)
     const uint2* s_mi = reinterpret_cast<const uint2*>(s_blob + L.mi);
     const uint8_t* s_st = s_blob + L.s0;                // stripe of state s at s_st + s * L.stripe
     const uint8_t* g_h2 = st.blob + L.h2;               // HBM/L2: [s][j][d]

@@ -83,6 +83,7 @@ def test_eight_shards_equal_one_handle_with_both_gathers():
     views = [p.begin() for p in pipes]
     recs = [StepRecord(SHARD, "cuda") for _ in range(WORLD)]
     gathers = [ObservationGather(recs[r], WORLD, dist_module=lb_s.rank(r)) for r in range(WORLD)]
+    works = [None] * WORLD
 
     whole.reset()
     for s in shards:
@@ -104,7 +105,10 @@ def test_eight_shards_equal_one_handle_with_both_gathers():
                 s.feedback_bytes_into(None)
                 s._obs, s._rew, s._done = recs[r].obs, recs[r].reward, recs[r].done
                 s.step(act)
-                gathers[r]()
+                works[r] = gathers[r](async_op=True)         # (one process plays all ranks: wait once every rank has joined)
+        if k >= K // 2:
+            for w in works:
+                w.wait()
         if k < K // 2 and (k + 1) % chunk == 0:              # a chunk was gathered: every rank holds the whole job's bytes
             b = (k // chunk) % 2
             k0 = k + 1 - chunk

@@ -916,10 +916,17 @@ int gw_selftest_runq(uint64_t seed, int32_t operations, int32_t mult, int32_t co
     GwTally tally = {0, 0, 0, 0, 0};
     uint64_t ref_drops = 0, ref_apps = 0;
     uint32_t ctr = 1, bad = 0;
+    int big_left = 6;
     for (int32_t op = 0; op < operations; ++op) {
         const uint32_t what = rnd(16);
         if (what < 8) {                                   // k counter ticks
-            const uint32_t k = 1 + rnd(what < 5 ? 3 : 22);
+            // mostly a step's worth of ticks; now and then a LONG step (a counter interval far below the step length):
+            // hundreds to tens of thousands of ticks in one call
+            uint32_t k = 1 + rnd(what < 5 ? 3 : 22);
+            if (what == 7 && rnd(4) == 0) {
+                k = 90 + rnd(400);
+                if (big_left > 0 && rnd(4) == 0) { k = 4000 + rnd(26000); --big_left; }   // (the reference deque pays k * mult pushes)
+            }
             uint32_t c = ctr;
             for (uint32_t t = 0; t < k; ++t) {
                 for (uint32_t j = 0; j < m; ++j) {

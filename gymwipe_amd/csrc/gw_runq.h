@@ -155,8 +155,23 @@ GW_HD void gw_runq_append_literal(GwRunQ& q, uint32_t size, uint64_t* ring)
 GW_HD void gw_runq_ticks(GwRunQ& q, uint32_t k, uint32_t c, uint32_t bound, uint32_t base_bytes, uint64_t* ring,
                          uint32_t mult, uint32_t inv20, GwTally& t)
 {
+    if (k == 0u || mult == 0u) return;
+    if (k > (uint32_t)GW_QUEUE_CAP) {
+        // A long step (counter_interval far below the step's length: thousands of ticks in one call).  Only the packets of
+        // the last ceil(CAP / mult) ticks can be in a deque(maxlen=CAP) afterwards: everything queued now and every packet
+        // of the earlier ticks is dropped on the way, so the queue restarts empty at the counter value those ticks left.
+        // (Appending all k * mult packets first and popping the surplus, as below, is exact only while the run arithmetic's
+        // reciprocal division holds -- (j + t) * mult < 2^20 -- which a call with more than ~4 000 ticks broke.)
+        const uint32_t keep = ((uint32_t)GW_QUEUE_CAP + mult - 1u) / mult;
+        const uint32_t skip = k - keep;
+        t.app += skip * mult;
+        t.drop += q.len + skip * mult;
+        q.state = 0u; q.len = 0u; q.M = 0u; q.mid_head = 0u;
+        q.H.n = 0u; q.T.n = 0u;
+        c = (bound - (c < bound ? c : bound)) > skip ? c + skip : bound;      // min(c + skip, bound) without overflow
+        k = keep;
+    }
     const uint32_t add = k * mult;
-    if (add == 0u) return;
     const uint32_t cap = base_bytes + bound;
     const uint32_t want = q.len + add;
     const uint32_t drops = want > (uint32_t)GW_QUEUE_CAP ? want - (uint32_t)GW_QUEUE_CAP : 0u;

@@ -295,6 +295,7 @@ static int receive(ectx* c, int j, double p, const txtimes* x, int hdr_bytes, in
     cto_vec* v = c->v;
     double rxj = v->rx[c->e * c->R + j];
     double br = v->cfg.bit_rate;
+    if (!(rxj - p >= 0)) v->flags[c->e] |= CTO_FLAG_REFEXC;  /* :168 `assert noisePower >= 0` -> AssertionError */
     double ber = ber_bpsk(v, p, rxj - p);                    /* :161-173 */
     double err = 0 + ber * (x->t_h - x->t_s) * br;           /* :180-188 at header end */
     double hdr_bits = (hdr_bytes * 8) * v->coded_factor;

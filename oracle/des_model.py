@@ -142,8 +142,8 @@ class Proc(Ev):
 
 
 class Sim:
-    def __init__(self):
-        self.now = 0
+    def __init__(self, initial_time=0):     # simpy.Environment(initial_time=0)
+        self.now = initial_time
         self._heap = []
         self._eid = 0
         self.n_popped = 0
@@ -431,6 +431,7 @@ class FsplLink:
         self.freq, self.a, self.b = freq, dev_a, dev_b
         self.extra = extra                  # dB of the pair's custom models (JoinedAttenuationModel), or None
         self.attenuation = 0
+        self.fspl = 0                       # the FsplAttenuation member's own value (AttenuationModel starts at 0, physical.py:322)
         self.n_changes = Notifier(sim)
         for dev in (dev_a, dev_b):          # physical.py:380-386
             dev.position.n_change.subscribe_callback(self._moved, extra=[dev])
@@ -442,9 +443,9 @@ class FsplLink:
 
     def _update(self):                      # attenuation_models.py:28-36
         pa, pb = self.a.position, self.b.position
-        if pa.same_as(pb):
-            return
-        att = 20 * log10(pa.distance_to(pb)) + 20 * log10(self.freq) - 147.55
+        if not pa.same_as(pb):              # co-located: the FSPL member returns without setting anything (:31-33) and keeps
+            self.fspl = 20 * log10(pa.distance_to(pb)) + 20 * log10(self.freq) - 147.55   # its previous value (0 at first)
+        att = self.fspl
         if self.extra:                      # physical.py:457: sum() over the models' values, FSPL first
             att = sum([att, self.extra])
         if att != self.attenuation:         # physical.py:354-362
@@ -737,8 +738,8 @@ class World:
     """One simulation: clock, band and the MAC address counter
     (simple_stack.py:374-384 keeps the latter in a class global)."""
 
-    def __init__(self):
-        self.sim = Sim()
+    def __init__(self, start_time=0):
+        self.sim = Sim(start_time)
         self.band = Band(self.sim)
         self._mac_ctr = 0
 
@@ -879,8 +880,10 @@ class CounterTrafficModel:
 
     def __init__(self, num_devices=2, positions=None, mult=None, dest=None,
                  rrm_pos=(0.0, 0.0), traffic=True, peer_receive=False,
-                 rx_duration=10, float_duration=False, extra_att=None, counter_interval=None):
-        """traffic=False: no counter processes, packets come from enqueue();
+                 rx_duration=10, float_duration=False, extra_att=None, counter_interval=None, start_time=0):
+        """start_time: the clock's initial value (test hook; the reference's SimMan.init() starts at 0,
+        simtools.py:90-95 -- everything else is unchanged, the first counter tick falls on it).
+        traffic=False: no counter processes, packets come from enqueue();
         peer_receive: every sender MAC is kept in receive mode (SURVEY 8f rank
         2; the reference env never does this); float_duration: the assignment
         duration is passed as a float, as test_stack.py:197 does, which makes
@@ -889,7 +892,7 @@ class CounterTrafficModel:
         positions = positions or circle_layout(D)
         mult = mult or default_multiplicity(D)
         dest = dest or [(i + 1) % D for i in range(D)]
-        self.world = World()
+        self.world = World(start_time)
         self.sim = self.world.sim
         self.senders = [_Sender(self.world, "Sender %d" % (i + 1),
                                 positions[i][0], positions[i][1], mult[i], traffic, counter_interval)

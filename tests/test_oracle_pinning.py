@@ -323,3 +323,89 @@ def test_transmission_ending_in_the_guard_slot(factor):
             in_guard += _event_time(tx) >= stopw
     assert (in_guard > 0) == (factor != 2082), in_guard
     assert int(co.get("flags")[0]) & (FLAG_CARRY | FLAG_REFEXC) == 0
+
+
+# ---- property-based layer 1 == layer 2 ------------------------------------------------------------------------------
+# Everything this repo claims beyond the reference's own asserted numbers (D = 4 / 16, resets, every f64 `now`, long rollouts)
+# rests on the flattened C restatement (layer 2: what the GPU is compared with) computing exactly what the statement-by-statement
+# event-driven restatement (layer 1) computes.  A seeded hypothesis differential over the whole configuration space of the
+# C-ABI: sender count, geometry -- drawn to include the decode thresholds (payload 3.41676 m, header 5.54584 m from the
+# talker), co-located radios and far-away ones --, multiplicities 0..5, destinations, custom attenuation per pair, start times
+# up to 1.2e6 s, random actions and per-step resets.  Compared after EVERY step: outputs, clock, counters, queue contents,
+# received values, the f64 received power of every radio (bit for bit), transmission counts, flags.
+from hypothesis import HealthCheck, given, settings, strategies as hst
+
+PAYLOAD_THRESHOLD_M, HEADER_THRESHOLD_M = 3.41676, 5.54584      # simple_stack.py:269-286 flips here (tests/test_gpu_parity.py MARGINAL)
+
+
+@hst.composite
+def _configs(draw):
+    D = draw(hst.integers(2, 8))
+    rrm = (draw(hst.sampled_from([0.0, 0.0, 0.5, -1.25])), draw(hst.sampled_from([0.0, 0.0, 0.75])))
+    pos = []
+    for i in range(D):
+        kind = draw(hst.sampled_from(["free", "free", "free", "payload", "header", "on_rrm", "on_peer", "far"]))
+        ang = draw(hst.integers(0, 6283)) / 1000.0           # (milliradians: no denormal coordinate offsets, whose distance underflows to 0)
+        if kind == "free":
+            r = draw(hst.floats(0.4, 9.0, allow_nan=False))
+        elif kind in ("payload", "header"):
+            base = PAYLOAD_THRESHOLD_M if kind == "payload" else HEADER_THRESHOLD_M
+            r = base * (1.0 + draw(hst.sampled_from([0.0, 1e-7, -1e-7, 1e-5, -1e-5, 2e-3, -2e-3])))
+        elif kind == "far":
+            r = draw(hst.floats(20.0, 400.0, allow_nan=False))
+        else:
+            r = 0.0
+        if kind == "on_peer" and pos:
+            pos.append(pos[draw(hst.integers(0, len(pos) - 1))])       # exactly on another sender: attenuation 0 dB
+        else:
+            pos.append((rrm[0] + r * np.cos(ang), rrm[1] + r * np.sin(ang)))
+    mult = [draw(hst.integers(0, 5)) for _ in range(D)]
+    dest = [draw(hst.integers(0, D - 1)) for _ in range(D)]
+    extra = {}
+    for _ in range(draw(hst.integers(0, 3))):
+        a, b = draw(hst.integers(0, D)), draw(hst.integers(0, D))
+        if a != b:
+            extra[(min(a, b), max(a, b))] = draw(hst.sampled_from([0.5, 1.25, 3.0, 7.5, 12.0]))
+    start = draw(hst.sampled_from([0.0, 0.0, 0.0, 1.0, 17.25, 1000.0, 65536.0, 123456.789, 999999.9993, 1.2e6]))
+    steps = draw(hst.integers(40, 100))
+    seed = draw(hst.integers(0, 2 ** 31 - 1))
+    p_reset = draw(hst.sampled_from([0.0, 0.02, 0.1, 0.3]))
+    return D, rrm, pos, mult, dest, extra, start, steps, seed, p_reset
+
+
+@settings(max_examples=600, deadline=None, derandomize=True, database=None,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much])
+@given(_configs())
+def test_property_based_layer2_equals_layer1(cfg):
+    D, rrm, pos, mult, dest, extra, start, steps, seed, p_reset = cfg
+    rng = np.random.default_rng(seed)
+    py = dm.CounterTrafficModel(D, positions=pos, mult=mult, dest=dest, rrm_pos=rrm, extra_att=extra or None, start_time=start)
+    co = CtOracle(1, D, config=default_config(D, positions=pos, mult=mult, dest=dest, rrm_pos=rrm, extra_att=extra or None,
+                                             start_time=start))
+    if rng.random() < 0.7:                                   # (the reference's own test never resets: counters start at 1)
+        assert py.reset() == co.reset()[0]
+    for k in range(steps):
+        if rng.random() < p_reset:
+            assert py.reset() == co.reset()[0]
+        d, du = int(rng.integers(0, D)), int(rng.integers(0, 20))
+        try:
+            o, r, dn, _ = py.step(d, du)
+        except AssertionError:
+            # `assert noisePower >= 0` (simple_stack.py:168): the reference itself raises here; layer 2 must say so
+            co.step([d], [du])
+            assert int(co.get("flags")[0]) & FLAG_REFEXC, "layer 1 raised at step %d, layer 2 did not flag it" % k
+            return
+        oc, rc, dc = co.step([d], [du])
+        s = py.snapshot()
+        where = "at step %d of %r" % (k, (cfg,))
+        assert (o, r, dn) == (int(oc[0]), float(rc[0]), bool(dc[0])), "outputs differ " + where
+        assert s["now"] == co.get("now")[0], "simulated time differs " + where
+        assert s["counters"] == co.get("counter")[0].tolist(), "counters differ " + where
+        assert s["qlen"] == co.get("qlen")[0].tolist(), "queue lengths differ " + where
+        assert s["received"] == co.get("received")[0].tolist(), "received values differ " + where
+        assert s["rx_power"] == co.get("rx_power")[0].tolist(), "rx power bits differ " + where
+        assert s["n_tx"] == int(co.get("n_tx")[0]), "transmission counts differ " + where
+        q = co.get("queue")[0]
+        for i in range(D):
+            assert s["queues"][i] == q[i][:s["qlen"][i]].tolist(), "queue %d differs %s" % (i, where)
+        assert int(co.get("flags")[0]) & (FLAG_CARRY | FLAG_REFEXC) == 0, "layer 2 flagged a step layer 1 completed " + where

@@ -69,6 +69,8 @@ struct cto_vec {
     uint64_t* n_app;      /* [n] queue appends                      */
     uint64_t* n_pop;      /* [n] queue pops                         */
     uint64_t* n_drop;     /* [n] drop-oldest events                 */
+    uint32_t* talked;     /* [n] bit r: radio r has transmitted, i.e. its attenuation models towards every other radio exist
+                           *     (AttenuationModelFactory.getInstance creates a pair's model at its first use, physical.py:500-528) */
 };
 
 /* ---- static tables ------------------------------------------------------ */
@@ -160,14 +162,50 @@ static void build_links(cto_vec* v)
         }
 }
 
-/* Position.set between two steps (devices/core.py:77-86): the links of the moved radio get new attenuations
- * (physical.py:380-386); nothing is on the air at a step boundary, so no reception is touched (simple_stack.py:119-128) */
-void cto_set_position(cto_vec* v, int radio, double x, double y)
+/* one pair's attenuation and link power from the current positions (both directions) */
+static void build_pair(cto_vec* v, int a, int b)
 {
-    if (!v || radio < 0 || radio >= v->R) return;
+    const cto_config* cfg = &v->cfg;
+    double att = fspl_db(cfg, a, b);
+    if (cfg->extra_att_db[a][b] != 0.0) {                    /* physical.py:457: sum() over [FSPL, custom models] */
+        volatile double joined = 0.0 + att;
+        joined = joined + cfg->extra_att_db[a][b];
+        att = joined;
+    }
+    v->att[a][b] = v->att[b][a] = att;
+    v->prx[a][b] = v->prx[b][a] = pow(10.0, (cfg->tx_power_dbm - att) / 10);
+}
+
+/* Position.set between two steps (devices/core.py:77-86): the attenuation models of the moved radio's pairs hear about it
+ * (physical.py:380-386) -- and, as in the reference,
+ *   * a pair whose new distance is >= STANDBY_THRESHOLD (3000 m, physical.py:371) does NOT update: the stale attenuation stays;
+ *   * a pair that now shares one position does not update either (FsplAttenuation._update returns without setting anything,
+ *     attenuation_models.py:31-33: the previous value stays, it does not become 0 dB);
+ *   * a pair whose model does not exist yet (neither radio has transmitted: models are created at first use) has nothing
+ *     to keep: it is created later from the positions of that moment.
+ * Nothing is on the air at a step boundary, so no reception is touched (simple_stack.py:119-128).
+ * Returns 0, or -2 when a keep-rule applies to a pair whose model exists in some envs of this handle and not in others (one
+ * shared geometry cannot represent that: use one handle per env). */
+int cto_set_position(cto_vec* v, int radio, double x, double y)
+{
+    if (!v || radio < 0 || radio >= v->R) return -1;
     v->cfg.pos[radio][0] = x;
     v->cfg.pos[radio][1] = y;
-    build_links(v);
+    for (int b = 0; b < v->R; ++b) {
+        if (b == radio) continue;
+        const double bx = v->cfg.pos[b][0], by = v->cfg.pos[b][1];
+        const int same = (x == bx && y == by);
+        const double dist = sqrt(pow(x - bx, 2.0) + pow(y - by, 2.0));    /* devices/core.py:88-95 */
+        const uint32_t pair = (1u << radio) | (1u << b);
+        int exists = (v->talked[0] & pair) != 0;
+        if (same || dist >= 3000.0) {
+            for (int64_t e = 1; e < v->n; ++e)
+                if (((v->talked[e] & pair) != 0) != exists) return -2;
+            if (exists) continue;                                         /* the stale value stays */
+        }
+        build_pair(v, radio, b);
+    }
+    return 0;
 }
 
 cto_vec* cto_create(const cto_config* cfg, int64_t n)
@@ -192,7 +230,7 @@ cto_vec* cto_create(const cto_config* cfg, int64_t n)
     ALLOC(v->latest, n);    ALLOC(v->last_abs, n);    ALLOC(v->done, n);
     ALLOC(v->rx, n * R);    ALLOC(v->flags, n);
     ALLOC(v->n_tx, n);      ALLOC(v->n_deliv, n);     ALLOC(v->n_app, n);
-    ALLOC(v->n_pop, n);     ALLOC(v->n_drop, n);
+    ALLOC(v->n_pop, n);     ALLOC(v->n_drop, n);      ALLOC(v->talked, n);
 #undef ALLOC
     for (int64_t e = 0; e < n; ++e) {
         v->now[e] = cfg->start_time;
@@ -211,7 +249,7 @@ void cto_destroy(cto_vec* v)
     free(v->now); free(v->wake); free(v->counter); free(v->q); free(v->qhead);
     free(v->qlen); free(v->rv); free(v->latest); free(v->last_abs); free(v->done);
     free(v->rx); free(v->flags); free(v->n_tx); free(v->n_deliv); free(v->n_app);
-    free(v->n_pop); free(v->n_drop);
+    free(v->n_pop); free(v->n_drop); free(v->talked);
     free(v);
 }
 
@@ -325,6 +363,7 @@ static void step_one(cto_vec* v, int64_t e, int d, int duration,
     int L = ndigits(slots);
     txtimes an = tx_times(v, t_a, mh, L);
     v->n_tx[e]++;
+    v->talked[e] |= 1u << RRM;                               /* every listener's model towards the RRM exists from here on */
     for (int j = 0; j < D; ++j) rx[j] = rx[j] + v->prx[RRM][j];       /* :130-139 */
     int granted = receive(&c, d, v->prx[RRM][d], &an, mh, L);
     for (int j = 0; j < D; ++j) rx[j] = rx[j] + (-v->prx[RRM][j]);    /* :146-154 */
@@ -354,6 +393,7 @@ static void step_one(cto_vec* v, int64_t e, int d, int duration,
             v->n_pop[e]++;
             txtimes x = tx_times(v, cur, mh, (int)s - mh);
             v->n_tx[e]++;
+            v->talked[e] |= 1u << d;
             for (int j = 0; j < R; ++j) if (j != d) rx[j] = rx[j] + v->prx[d][j];
             int ok = receive(&c, RRM, v->prx[d][RRM], &x, mh, (int)s - mh);
             for (int j = 0; j < R; ++j) if (j != d) rx[j] = rx[j] + (-v->prx[d][j]);

@@ -60,7 +60,7 @@ int  cto_config_default(cto_config* cfg, int num_devices);
 cto_vec* cto_create(const cto_config* cfg, int64_t num_envs);
 void cto_destroy(cto_vec* v);
 /* Position.set(x, y) on one radio of EVERY env of the handle, between two steps (devices/core.py:77-86) */
-void cto_set_position(cto_vec* v, int radio, double x, double y);
+int cto_set_position(cto_vec* v, int radio, double x, double y);   /* 0, or -2: one shared geometry cannot represent the move (see ct_oracle.c) */
 
 /* reset(): counters <- 0, interpreter <- 0, NO time rewind (counter_traffic.py:135-144).
  * mask may be NULL (all envs).  obs_out may be NULL. */

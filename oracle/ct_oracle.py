@@ -72,7 +72,7 @@ def lib():
         L.cto_destroy.argtypes = [C.c_void_p]
         L.cto_destroy.restype = None
         L.cto_set_position.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
-        L.cto_set_position.restype = None
+        L.cto_set_position.restype = C.c_int
         L.cto_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cto_reset.restype = None
         L.cto_step.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
@@ -160,7 +160,10 @@ class CtOracle:
 
     def set_position(self, radio, x, y):
         """Position.set on one radio of every env of this handle (between steps)."""
-        lib().cto_set_position(self._h, int(radio), float(x), float(y))
+        rc = lib().cto_set_position(self._h, int(radio), float(x), float(y))
+        if rc:
+            raise ValueError("cto_set_position: %s" % ("bad radio index" if rc == -1 else
+                             "a keep-the-stale-attenuation rule applies to a pair whose model exists in some envs only: one handle per env"))
 
     def reset(self, mask=None):
         obs = np.empty(self.n, np.int32)

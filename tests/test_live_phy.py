@@ -62,6 +62,65 @@ def test_c_oracle_position_change_matches_layer1():
     assert int(orc.get("n_delivered")[0]) > 0
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_c_oracle_moves_past_standby_and_onto_other_radios_match_layer1(seed):
+    """The two keep-the-stale-value rules of the reference's positional models, and their interplay with lazily created models
+    (physical.py:364-397,500-528; attenuation_models.py:28-36): a move that leaves a pair >= 3000 m apart, or on one spot,
+    does NOT update that pair's attenuation -- if its model exists already (one of the two radios has transmitted); a model
+    created later takes the positions of that moment.  Random move scripts (near, > 3 km, onto another radio, back again,
+    before and after the radios' first transmissions) on layer 1's live Position / FsplLink objects vs cto_set_position."""
+    from oracle.ct_oracle import CtOracle, default_config
+    from oracle.des_model import CounterTrafficModel
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.integers(2, 5))
+    pos = [(float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))) for _ in range(D)]
+    rrm = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)))
+    mult = [int(rng.integers(1, 4)) for _ in range(D)]
+    model = CounterTrafficModel(D, positions=pos, rrm_pos=rrm, mult=mult)
+    orc = CtOracle(1, D, config=default_config(D, positions=pos, rrm_pos=rrm, mult=mult))
+    radios = model.senders + [model.rrm]
+    cur = pos + [rrm]
+    K = 70
+    dev, dur = action_stream(seed, K, 1, D)
+    if seed % 2:
+        assert model.reset() == int(orc.reset()[0])
+    kinds = 0
+    for k in range(K):
+        if rng.random() < (0.6 if k < 6 else 0.25):                     # early moves: before most models exist
+            r = int(rng.integers(0, D + 1))
+            kind = rng.choice(["near", "far", "onto", "near", "back"])
+            if kind == "near":
+                x, y = float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4))
+            elif kind == "far":
+                x, y = float(rng.choice([-1, 1]) * rng.uniform(3100, 9000)), float(rng.uniform(-50, 50))
+            elif kind == "onto":
+                x, y = cur[int(rng.choice([i for i in range(D + 1) if i != r]))]
+            else:
+                x, y = (pos + [rrm])[r]
+            radios[r].position.set(x, y)
+            orc.set_position(r, x, y)
+            cur[r] = (x, y)
+            kinds |= {"near": 1, "far": 2, "onto": 4, "back": 8}[kind]
+        try:
+            o, rw, dn, _ = model.step(int(dev[k, 0]), int(dur[k, 0]))
+        except AssertionError:                                          # negative noise power: the reference raises too
+            orc.step(dev[k], dur[k])
+            assert int(orc.get("flags")[0]) & 2
+            return
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (o, float(rw), bool(dn)) == (int(oo[0]), float(orr[0]), bool(od[0])), k
+        snap = model.snapshot()
+        assert snap["now"].hex() == float(orc.get("now")[0]).hex(), k
+        assert snap["qlen"] == orc.get("qlen")[0].tolist() and snap["received"] == orc.get("received")[0].tolist(), k
+        assert [v.hex() for v in snap["rx_power"]] == [float(v).hex() for v in orc.get("rx_power")[0]], k
+    # every attenuation model layer 1 has created agrees with layer 2's table for that pair
+    ids = {id(r): i for i, r in enumerate(radios)}
+    for key, link in model.world.band._links.items():
+        a, b = [ids[x] for x in key]
+        assert float(link.attenuation).hex() == float(orc.attenuation(a, b)).hex(), (a, b)
+    assert kinds & 6                                                    # the script did move something far away or onto a radio
+
+
 def test_open_noise_state_layouts_are_accepted_not_refused(native_lib):
     import ctypes as C
     from gymwipe_amd import _native

@@ -148,12 +148,59 @@ __device__ __forceinline__ double ber_bpsk_dev(double sig_mw, double noise_mw, d
     return (1 - pow(e, -1.4 * x)) * pow(e, -(pow(x, 2.0) / 2)) / (1.135 * sqrt2pi * x);
 }
 
-// link power from -> to (mW) of env e: per-env table [from][to][N] or the handle's shared [from][to]
+// link power from -> to (mW) of env e: the env's own matrix (row = talker) or the handle's shared [from][to]
 template <bool PER_ENV>
 __device__ __forceinline__ double gw_link(const GwState& st, int R, int from, int to, uint32_t e)
 {
-    if (PER_ENV) return st.prx_env[((size_t)(from * R + to)) * (size_t)st.N + e];
+    if (PER_ENV) return st.prx_env[((size_t)e * R + from) * gw_rp(R) + to];
     return st.prx_tab[from * R + to];
+}
+// phy._receivedPower of radio j of env e (rows of gw_rp(R) doubles)
+__device__ __forceinline__ double& gw_rx(const GwState& st, int R, int j, int64_t e)
+{
+    return st.rxp[(size_t)e * gw_rp(R) + j];
+}
+
+
+// ---- the per-step kernels' arguments and the header in front of the `ip` records (gw_internal.h: gw_blob_header) ----
+// Only what changes per call and the addresses of the wave's first loads are arguments -- under 100 bytes.  Everything else
+// (the handle's GwDevConst and GwState, the tables) sits in the header of the `ip` allocation and is read from there by
+// scalar loads.
+//  * As leading scalar arguments the values below are PRELOADED into SGPRs by the command processor
+//    (-amdgpu-kernarg-preload-count, Makefile; 14 dwords at most), so the table and state loads issue in the wave's first
+//    cycles; read from a GwState in the kernel-argument segment they cost two scalar-cache round trips before the first
+//    vector load could leave.  The constants are fetched under the shadow of those loads.
+//  * On the host, a launch with both structs by value (1.2 KB) spent 3.6 us of its 5.5 us writing arguments into
+//    device-visible memory (tools/launch_floor.hip).
+#define GW_LEAD_PARAMS uint32_t* __restrict__ ip, double* __restrict__ tw, uint32_t* __restrict__ tk, uint8_t* __restrict__ qb, \
+                       const int32_t* __restrict__ device, const int32_t* __restrict__ duration, uint32_t n_envs, uint32_t dev_stage
+// dev_stage: sender count | chunks of the tables to stage << 8 (one argument: the preload window holds 14 dwords)
+#define GW_LEAD_ARGS(st_) (st_).ip, (st_).tw, (st_).tk, (st_).qb, device, duration, (uint32_t)(st_).N, \
+                          ((uint32_t)(st_).D | ((uint32_t)(st_).stage_chunks << 8))
+// (read through the CONSTANT address space: nothing writes the header while a step kernel runs, and as constant-space
+//  loads the reads become scalar loads that the compiler may issue anywhere -- in particular at the top of the wave)
+// (the host pass of the compiler parses these device functions too and has no address spaces: plain types there)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GW_AS_CONST __attribute__((address_space(4)))
+#else
+#define GW_AS_CONST
+#endif
+template <int DT>
+__device__ __forceinline__ GwDevConst hdr_const(const uint32_t* ip, int n_dev)
+{
+    const int D = DT > 0 ? DT : n_dev;
+    const uint8_t* at = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(D) + gw_hdr_cst_off(D);
+    return *(const GW_AS_CONST GwDevConst*)at;                                   // (only the fields the body uses are loaded)
+}
+template <int DT>
+__device__ __forceinline__ GwState hdr_state(uint32_t* ip, double* tw, uint32_t* tk, uint8_t* qb, uint32_t n_envs, int n_dev)
+{
+    const int D = DT > 0 ? DT : n_dev;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(D);
+    GwState st = *(const GW_AS_CONST GwState*)(base + gw_hdr_st_off(D));
+    st.ip = ip; st.tw = tw; st.tk = tk; st.qb = qb; st.N = (int64_t)n_envs; st.D = D;
+    st.blob = base;
+    return st;
 }
 
 __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 len(str(value)), v >= 0

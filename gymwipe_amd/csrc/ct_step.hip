@@ -128,11 +128,11 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             bool granted;
             if (DYN) {                                           // simple_stack.py:82 (+p), :166-167 (noise = received - signal), :154 (-p)
                 const double p_a = lp(RRM, d);
-                const double up = st.rxp[(size_t)d * N + e] + p_a;
+                const double up = gw_rx(st, R, d, e) + p_a;
                 const double noise = up - p_a;
                 if (!(noise >= 0.0)) fl |= GW_FLAG_REFEXC;
                 granted = receive(m, ber_bpsk_dev(p_a, noise, c.ten_log_br), an, br, hdr_bits, (double)(La * 8) * c.coded_factor, fl);
-                st.rxp[(size_t)d * N + e] = up + (-p_a);
+                gw_rx(st, R, d, e) = up + (-p_a);
             } else {
                 s_d_old = st.rxs[(int64_t)d * N + e];
                 s_d = s_h1[d * S + s_d_old];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             // live PHY: the RRM's (and a receive-mode peer's) received power, and the BER cached per noise value
             double rx_r = 0.0, rx_r0 = 0.0, p_x = 0.0, ber_xd = 0.0, nz_r_prev = -1.0;
             double rx_p = 0.0, rx_p0 = 0.0, p_p = 0.0, ber_pd = 0.0, nz_p_prev = -1.0;
-            if (DYN) { rx_r = rx_r0 = st.rxp[(size_t)RRM * N + e]; p_x = lp(d, RRM); }
+            if (DYN) { rx_r = rx_r0 = gw_rx(st, R, RRM, e); p_x = lp(d, RRM); }
             // receive-mode MAC at the destination (simple_stack.py:443-448): it is idle during d's window (its own
             // window, the only thing that blocks its phyIn handler, ended a slot before the previous step did)
             const int j_peer = (c.peer_receive && c.dest[d] != d) ? c.dest[d] : -1;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             uint32_t n_peer = 0;
             if (j_peer >= 0) {
                 if (DYN) {
-                    rx_p0 = st.rxp[(size_t)j_peer * N + e];
+                    rx_p0 = gw_rx(st, R, j_peer, e);
                     const double pa = lp(RRM, j_peer);
                     rx_p = (rx_p0 + pa) + (-pa);                              // it heard the announcement too
                     p_p = lp(d, j_peer);
@@ -312,14 +312,15 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
 
             // ---- rx-power state of every radio (simple_stack.py:130-157) ---------------------
             if (DYN) {
-                if (rx_r != rx_r0) st.rxp[(size_t)RRM * N + e] = rx_r;
+                if (st.talk) st.talk[e] |= (1ull << RRM) | (n_data ? (1ull << d) : 0ull);   // whose attenuation models exist now
+                if (rx_r != rx_r0) gw_rx(st, R, RRM, e) = rx_r;
                 if (j_peer >= 0) {
-                    if (rx_p != rx_p0) st.rxp[(size_t)j_peer * N + e] = rx_p;
+                    if (rx_p != rx_p0) gw_rx(st, R, j_peer, e) = rx_p;
                     if (n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
                 }
                 for (int j = 0; j < D; ++j) {
                     if (j == d || j == j_peer) continue;
-                    const double a0 = st.rxp[(size_t)j * N + e];
+                    const double a0 = gw_rx(st, R, j, e);
                     const double pa = lp(RRM, j);
                     double a = (a0 + pa) + (-pa);
                     if (n_data) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                         }
                     }
                     if (!(a >= 0.0)) fl |= GW_FLAG_REFEXC;
-                    if (a != a0) st.rxp[(size_t)j * N + e] = a;
+                    if (a != a0) gw_rx(st, R, j, e) = a;
                 }
             } else {
                 if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement

@@ -9,10 +9,24 @@
 //     attenuation_models.py:28-36): link powers per env, rebuilt on the device by gw_set_position(s).
 // MAC queues keep the exact suffix encoding of the default kernel (gw_queue.h): queues do not depend on the PHY.
 // (With GW_CFG_EXPLICIT_QUEUE the same live PHY runs inside the generic kernel: ct_step.hip, instantiation DYN.)
-// Same walk as ct_step_sfx.hip; what differs is A.2/A.4: every transmission i -> j adds its
-// power to the listeners' received power, the receiver's BER is physical.py:25-58,208-212 on the device libm
-// (log10 / pow / sqrt: last-ulp differences from CPython's libm -- they only enter error sums that are rounded to
-// integers, so decisions agree except on a measure-zero boundary), and the power is subtracted again.
+//
+// The step is the default kernel's walk with A.2 / A.4 done in f64, in two parts:
+//   WALK, one lane per env: announcement, window, counter ticks, interpreter -- serial per env.  The two receptions that
+//     decide anything (the addressed sender hears the RRM, the RRM hears the sender's data) take their BER from a per-link
+//     cache keyed by the noise power (GwState::bcache): BpskMcs.calculateBitErrorRate (physical.py:25-58,208-212) is
+//     evaluated only when a link meets a noise value it has not just seen.
+//   ALL-PAIRS, every OTHER radio j heard the announcement and, if any, d's n data packets (simple_stack.py:99-157):
+//     rx_j <- (rx_j + p(RRM, j)) - p(RRM, j), then n times (rx_j + p(d, j)) - p(d, j) (a fixed point ends it).
+//       D <= 6: the lane that walked the env does it, from its env's rows held in registers (16-byte loads);
+//       D = 8, 16, 32: the wave re-maps its 64 lanes to groups of D lanes, one group per env and one lane per radio, D passes
+//         over the wave's 64 envs: every load and store covers the contiguous rows of 64 / D envs, the talker and packet
+//         count of the group's env come by wave shuffle from the lane that walked it, and the listeners' "the reference
+//         would raise" bits are OR-reduced across the group (__shfl_xor butterfly) into one atomic per env.
+//     With per-env geometry this part is what moves the bytes (D = 16: three 144-byte rows per env and step); thread-per-env
+//     with a serial loop over listeners read them as 64 scattered 8-byte accesses per instruction.
+// Device libm where the reference calls libm (log10, 10**x, e**x, sqrt): last-ulp differences from CPython's only enter
+// error sums that are rounded to integers, so decisions agree except on a measure-zero boundary; with the host's link
+// tables (no per-env geometry) the received powers themselves are exact sums and compare bit for bit.
 #include "ct_common.hip.h"
 #include "gw_queue.h"
 
@@ -21,46 +35,157 @@ using namespace gwk;
 namespace {
 
 template <class T>
-__device__ __forceinline__ T ld(const void* base, uint32_t byte_off)
+__device__ __forceinline__ T ld(const void* base, size_t byte_off)
 {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 template <class T>
-__device__ __forceinline__ void st_(void* base, uint32_t byte_off, const T& v)
+__device__ __forceinline__ void st_(void* base, size_t byte_off, const T& v)
 {
-    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+    gwk::gw_store_wt(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
+}
+__device__ __forceinline__ uint32_t word_of(const uint4& w, int i)          // i compile-time after unrolling
+{
+    return i == 0 ? w.x : (i == 1 ? w.y : (i == 2 ? w.z : w.w));
+}
+__device__ __forceinline__ double half_of(const double2& v, int i) { return i ? v.y : v.x; }
+
+// physical.py:25-58 (Eb/N0, Q approximation), :82-98 (dBm helpers), :208-212 (BPSK).  exp10 / exp instead of pow(10, .) /
+// pow(e, .): the same function values up to the device libm's last ulp (see the header), a third of the instructions.
+__device__ __forceinline__ double ber_live(double sig_mw, double noise_mw, double ten_log_br)
+{
+    const double s = 10 * log10(sig_mw);
+    const double n = 10 * log10(noise_mw);
+    if (s <= n) return 0.5;
+    const double ratio = exp10((s - n - ten_log_br) / 10);
+    const double x = sqrt(2 * ratio);
+    const double sqrt2pi = 2.5066282746310002;
+    return (1 - exp(-1.4 * x)) * exp(-((x * x) / 2)) / (1.135 * sqrt2pi * x);
 }
 
-template <bool PER_ENV>
-__global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst c,
-                                                          const int32_t* __restrict__ device,
-                                                          const int32_t* __restrict__ duration,
-                                                          int32_t* __restrict__ obs,
-                                                          float* __restrict__ reward,
-                                                          uint8_t* __restrict__ done)
+// BER of a link at a noise power, through the link's one-entry cache {noise, ber}
+__device__ __forceinline__ double ber_cached(double2& entry, bool& dirty, double sig, double noise, double ten_log_br)
 {
-    const uint32_t N = (uint32_t)st.N;
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
-    const int D = c.D, R = D + 1, RRM = D;
-    const uint32_t RB = (uint32_t)st.RB;
-    const uint32_t o16 = e << 4, oq = e * RB;
+    if (noise == entry.x) return entry.y;
+    entry.x = noise;
+    entry.y = ber_live(sig, noise, ten_log_br);
+    dirty = true;
+    return entry.y;
+}
 
-    const int d = device[e];
-    const int du = duration[e];
-    const uint4 ip = ld<uint4>(st.ip, o16);
-    const double2 tw = ld<double2>(st.tw, o16);
-    const uint4 tk = ld<uint4>(st.tk, o16);
+// one listener's received power after the announcement and n data packets of d (simple_stack.py:130-157)
+__device__ __forceinline__ double heard(double a0, double pa, double pd, int n)
+{
+    double a = (a0 + pa) + (-pa);
+    for (int i = 0; i < n; ++i) {
+        const double b = (a + pd) + (-pd);
+        if (b == a) break;                                       // a fixed point of the (+p, -p) pair stays one
+        a = b;
+    }
+    return a;
+}
+
+// DT > 0: compile-time sender count, the qb record and (DT <= 6) the env's PHY rows in registers; DT == 0: any count.
+template <int DT, bool PER_ENV>
+__global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_t* __restrict__ obs, float* __restrict__ reward,
+                                                         uint8_t* __restrict__ done)
+{
+    const int n_dev = (int)(dev_stage & 0xffu);
+    const GwState st = hdr_state<DT>(ip, tw, tk, qb, n_envs, n_dev);
+    const GwDevConst c = hdr_const<DT>(ip, n_dev);
+    // (the arrays of the constants are indexed by the lane's action: through a pointer, as memory reads -- indexing the by-value
+    //  copy would put it on the stack)
+    const GwDevConst* cp = reinterpret_cast<const GwDevConst*>(reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(DT > 0 ? DT : n_dev) +
+                                                               gw_hdr_cst_off(DT > 0 ? DT : n_dev));
+    constexpr bool PACKED = DT > 0;
+    constexpr bool ROWS = DT > 0 && DT <= 6;                     // the env's rows in the walking lane's registers
+    constexpr bool COOP = DT >= 8;                               // all-pairs part by groups of DT lanes
+    const int D = DT > 0 ? DT : c.D;
+    const int R = D + 1, RRM = D;
+    constexpr int NWC = DT > 0 ? (2 * DT + 1 + 15) / 16 : 1;
+    constexpr int RPC = DT > 0 ? ((DT + 2) & ~1) : 2;            // gw_rp(R) at compile time
+    const int RP = DT > 0 ? RPC : gw_rp(R);
+    constexpr int NH = RPC / 2;                                  // double2 chunks of a row
+    const uint32_t N = n_envs;
+    const uint32_t e = blockIdx.x * 64u + threadIdx.x;
+    const bool live = e < N;
+    const uint32_t el = live ? e : 0u;
+    const uint32_t RB = PACKED ? 16u * NWC : (uint32_t)st.RB;
+    const size_t o16 = (size_t)el << 4, oq = (size_t)el * RB;
+    const size_t orx = (size_t)el * RP * 8u;                     // the env's row of received powers
+    const size_t olk = (size_t)el * R * RP * 8u;                 // the env's link matrix (PER_ENV)
+
+    // shared geometry: the handle's [R][R] link table -> LDS once per workgroup
+    __shared__ double s_prx[PER_ENV ? 1 : (GW_MAX_RADIOS * GW_MAX_RADIOS)];
+    if (!PER_ENV) {
+        for (int i = threadIdx.x; i < R * R; i += 64) s_prx[i] = st.prx_tab[i];
+    }
+
+    // ---- loads, all issued before anything is waited for ---------------------------------------------------------------
+    int d = device[el];
+    int du = duration[el];
+    uint4 bp = ld<uint4>(st.ip, o16);
+    const double2 tw0 = ld<double2>(st.tw, o16);
+    const uint4 tk0 = ld<uint4>(st.tk, o16);
+    uint4 qw[NWC];
+#pragma unroll
+    for (int w = 0; w < NWC; ++w) qw[w] = PACKED ? ld<uint4>(st.qb, oq + 16u * w) : make_uint4(0u, 0u, 0u, 0u);
+    double2 rxv[ROWS ? NH : 1], pav[ROWS && PER_ENV ? NH : 1];
+    if (ROWS) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) rxv[h] = ld<double2>(st.rxp, orx + 16u * h);
+        if (PER_ENV) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) pav[h] = ld<double2>(st.prx_env, olk + ((size_t)RRM * RP) * 8u + 16u * h);
+        }
+    }
+    asm volatile("" : "+v"(d), "+v"(du));
+    asm volatile("" : "+v"(bp.x), "+v"(bp.y), "+v"(bp.z), "+v"(bp.w));
+    __syncthreads();                                             // s_prx
+
+    const bool bad = (unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration;
+    const int dq = bad ? 0 : d;                                   // a valid index for the dependent loads below
+    // dependent on the action: the two cache entries, the talker's row (its link to every listener) and, unless the rows
+    // are in registers already, the four scalars of the two deciding receptions
+    double2 ca = ld<double2>(st.bcache, ((size_t)el * 2 * D + dq) * 16u);
+    double2 cx = ld<double2>(st.bcache, ((size_t)el * 2 * D + D + dq) * 16u);
+    double2 pdv[ROWS && PER_ENV ? NH : 1];
+    if (ROWS && PER_ENV) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) pdv[h] = ld<double2>(st.prx_env, olk + ((size_t)dq * RP) * 8u + 16u * h);
+    }
+    auto link = [&](int from, int to) -> double {
+        return PER_ENV ? st.prx_env[((size_t)el * R + from) * RP + to] : s_prx[from * R + to];
+    };
+    double rx_d0, rx_r0, p_a, p_x;
+    if (ROWS) {
+        rx_d0 = 0.0; rx_r0 = half_of(rxv[RRM >> 1], RRM & 1);
+#pragma unroll
+        for (int j = 0; j < DT; ++j) rx_d0 = (j == dq) ? half_of(rxv[j >> 1], j & 1) : rx_d0;
+        if (PER_ENV) {
+            p_a = 0.0;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) p_a = (j == dq) ? half_of(pav[j >> 1], j & 1) : p_a;
+            p_x = half_of(pdv[RRM >> 1], RRM & 1);
+        } else {
+            p_a = link(RRM, dq); p_x = link(dq, RRM);
+        }
+    } else {
+        rx_d0 = st.rxp[(size_t)el * RP + dq];
+        rx_r0 = st.rxp[(size_t)el * RP + RRM];
+        p_a = link(RRM, dq); p_x = link(dq, RRM);
+    }
 
     const StepMath m(c);
-    uint32_t rvm = tk.z;                          // (record layout: ct_step_sfx.hip)
-    int32_t last_abs = (int32_t)(tk.w & 0x7fffffffu);
-    uint32_t dn = tk.w >> 31;
-    uint32_t fl = 0, k_bad = 0;
-    Tally k = {0, 0, 0, 0, 0};
+    uint32_t rvm = tk0.z;                                         // (record layout: ct_step_sfx.hip)
+    int32_t last_abs = (int32_t)(tk0.w & 0x7fffffffu);
+    uint32_t dn = tk0.w >> 31;
+    uint32_t fl = 0, k_bad = 0, k_pop = 0, k_deliv = 0;
     const int pv = c.payload_value;
+    int n_data = 0;                                               // data packets of d this step (0 for a bad action / dead lane)
+    double rx_d = rx_d0, rx_r = rx_r0;
 
-    if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
+    if (live && bad) {
         // counter_traffic.py:147 asserts; a batched step cannot raise per env: flag + skip
         fl = GW_FLAG_BADACT;
         k_bad = 1;
@@ -68,45 +193,50 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         obs[e] = latest + c.counter_bound;
         reward[e] = 0.0f;
         done[e] = (uint8_t)dn;
-    } else {
+    } else if (live) {
         const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
+        const double ten_log_br = c.ten_log_br, coded_factor = c.coded_factor;
         const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
         const int mh = c.mac_hdr;
-        const double ten_log_br = c.ten_log_br;
 
-        uint32_t len_d = st.qb[oq + (uint32_t)d];
-        const uint32_t mult_d = (uint32_t)c.mult[d], inv16_d = c.inv16[d];
-        const double t_a = tw.x;
-        double wake = tw.y;
-        const uint32_t tau0 = tk.x, nbp = tk.y;
+        uint32_t nb[PACKED ? 16 * NWC : 1];
+        uint32_t len_d = 0;
+        if (PACKED) {
+#pragma unroll
+            for (int b = 0; b < 16 * NWC; ++b) nb[b] = (word_of(qw[b >> 4], (b >> 2) & 3) >> ((b & 3) * 8)) & 0xffu;
+#pragma unroll
+            for (int i = 0; i < DT; ++i) len_d = (i == d) ? nb[i] : len_d;
+        } else {
+            len_d = st.qb[oq + (uint32_t)d];
+        }
+        const uint32_t mult_d = (uint32_t)cp->mult[d], inv16_d = cp->inv16[d];
+        const double t_a = tw0.x;
+        double wake = tw0.y;
+        const uint32_t tau0 = tk0.x, nbp = tk0.y;
         GwBp bpc, bpp;
-        bpc.t0 = ip.x; bpc.c0 = ip.y;
-        bpp.t0 = ip.z; bpp.c0 = ip.w;
+        bpc.t0 = bp.x; bpc.c0 = bp.y;
+        bpp.t0 = bp.z; bpp.c0 = bp.w;
         const GwBp* hist = st.bph + ((size_t)e << 7);
-
         const int slots = du * c.duration_factor;                         // counter_traffic.py:149
 
         // ---- A.1 / A.2: announcement, heard by the addressed sender ------------------------------------
         const int Ld = ndigits(slots);
         const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(Ld * 8)));
-        k.tx++;
-        const double p_a = gw_link<PER_ENV>(st, R, RRM, d, e);               // simple_stack.py:111
-        const double rx_d0 = st.rxp[(size_t)d * N + e];
-        const double up_d = rx_d0 + p_a;                                  // :82  (+p) at the start of the transmission
+        const double up_d = rx_d0 + p_a;                                  // simple_stack.py:82  (+p) at the start
         const double noise_d = up_d - p_a;                                // :166-167 noise = received - signal
         if (!(noise_d >= 0.0)) fl |= GW_FLAG_REFEXC;                      // :168 assert noisePower >= 0
-        const double ber_a = ber_bpsk_dev(p_a, noise_d, ten_log_br);
-        const bool granted = receive(m, ber_a, an, br, hdr_bits, (double)(Ld * 8) * c.coded_factor, fl);
+        bool ca_dirty = false, cx_dirty = false;
+        const double ber_a = ber_cached(ca, ca_dirty, p_a, noise_d, ten_log_br);
+        const bool granted = receive(m, ber_a, an, br, hdr_bits, (double)(Ld * 8) * coded_factor, fl);
         if (!(an.t_e >= an.stop)) fl |= GW_FLAG_REFEXC;
-        st.rxp[(size_t)d * N + e] = up_d + (-p_a);                        // :154 (-p) when it completes
+        rx_d = up_d + (-p_a);                                             // :154 (-p) when it completes
         const double t_r = an.t_e;
         const double t_end = t_r + (double)(slots + 1) * slot;            // simple_stack.py:557-558
 
-        // ---- A.3: window at sender d -------------------------------------------------------------------
+        // ---- counter ticks: one jump per call where the step qualifies (gw_fastmath.h), else the running-sum loop -----
         uint32_t tau = tau0;
-        int n_data = 0;
-        Tally kd = {0, 0, 0, 0, 0};
-        auto ticks_to = [&](double t, bool inclusive) __attribute__((always_inline)) {
+        GwTally kd = {0, 0, 0, 0, 0};
+        auto ticks_to = [&](double t, bool inclusive) {
             uint32_t kk = 0;
             for (;;) {
                 const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
@@ -114,7 +244,8 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
                 const bool b1 = inclusive ? (w1 <= t) : (w1 < t);
                 const bool b2 = inclusive ? (w2 <= t) : (w2 < t);
                 const bool b3 = inclusive ? (w3 <= t) : (w3 < t);
-                if (inclusive && (wake == t || w1 == t || w2 == t || w3 == t)) fl |= GW_FLAG_TIE;
+                const double last = b3 ? w3 : (b2 ? w2 : (b1 ? w1 : wake));
+                if (inclusive && b0 && last == t) fl |= GW_FLAG_TIE;
                 kk += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;
                 wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
                 if (!b3) break;
@@ -122,16 +253,29 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
             tau += kk;
             len_d = gw_len_after_ticks(len_d, kk, mult_d, kd);
         };
+        double delta = 0.0;
+        const bool span_ok = c.fast_ticks && gw_tick_span_ok(wake, t_end, interval, &delta);
+        auto ticks_upto = [&](double t, bool inclusive) {
+            uint32_t nj = 0;
+            double wj = wake;
+            bool tiej = false, sane = false;
+            gw_tick_jump_lo(wake, t, delta, c.inv_interval_lo, inclusive, &nj, &wj, &tiej, &sane);
+            if (span_ok && sane) {
+                wake = wj;
+                tau += nj;
+                if (tiej) fl |= GW_FLAG_TIE;
+                len_d = gw_len_after_ticks(len_d, nj, mult_d, kd);
+            } else {
+                ticks_to(t, inclusive);
+            }
+        };
 
-        const double p_x = gw_link<PER_ENV>(st, R, d, RRM, e);               // the RRM hears sender d
-        double rx_r = st.rxp[(size_t)RRM * N + e];
-        const double rx_r0 = rx_r;
-        double ber_x = 0.0, noise_prev = -1.0;
+        // ---- A.3 / A.4: window at sender d, every data packet heard by the RRM -----------------------------------
         if (granted) {
             const double total = (double)slots * slot;                    // simple_stack.py:400
             const double stopw = t_r + total;                             // :401
             double cur = t_r;
-            ticks_to(cur, false);                                         // the MAC's process initialisation is URGENT
+            ticks_upto(cur, false);                                       // the MAC's process initialisation is URGENT
             for (;;) {
                 if (len_d == 0) {                                         // :409-416
                     if (mult_d != 0u && wake < stopw) {
@@ -146,67 +290,90 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
                 const double need = m.over_rate((double)(s * 8u));        // messages.py:67-75
                 if (!((stopw - cur) > need)) break;                       // :418-420
                 len_d--;                                                  // :425
-                k.pop++;
+                k_pop++;
                 const int pay = (int)s - mh;
                 const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
-                k.tx++;
                 n_data++;
                 const double up = rx_r + p_x;
                 const double noise = up - p_x;
                 if (!(noise >= 0.0)) fl |= GW_FLAG_REFEXC;
-                if (noise != noise_prev) { ber_x = ber_bpsk_dev(p_x, noise, ten_log_br); noise_prev = noise; }
+                const double ber_x = ber_cached(cx, cx_dirty, p_x, noise, ten_log_br);
                 if (!(x.t_e >= x.stop)) fl |= GW_FLAG_REFEXC;
-                const bool ok = receive(m, ber_x, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl);
+                const bool ok = receive(m, ber_x, x, br, hdr_bits, (double)(pay * 8) * coded_factor, fl);
                 rx_r = up + (-p_x);
-                k.deliv += ok ? 1u : 0u;                                  // devices.py:163-168, counter_traffic.py:75-80
+                k_deliv += ok ? 1u : 0u;                                  // devices.py:163-168, counter_traffic.py:75-80
                 rvm |= ok ? (1u << d) : 0u;
                 dn = (ok && pv == c.counter_bound) ? 1u : dn;
                 fl |= !(x.t_e < t_end) ? (uint32_t)GW_FLAG_CARRY : 0u;
-                ticks_to(x.t_e, true);
+                ticks_upto(x.t_e, true);
                 cur = x.t_e;
                 if (!(cur < stopw)) break;
             }
         }
-        if (rx_r != rx_r0) st.rxp[(size_t)RRM * N + e] = rx_r;
-
         // ---- A.5: remaining ticks up to the end of the step ------------------------------------------------
-        {
-            uint32_t nj = 0;
-            double wj = wake;
-            bool tiej = false;
-            if (c.fast_ticks && gw_tick_jump(wake, t_end, interval, c.inv_interval, true, &nj, &wj, &tiej)) {
-                wake = wj;
-                tau += nj;
-                if (tiej) fl |= GW_FLAG_TIE;
-                len_d = gw_len_after_ticks(len_d, nj, mult_d, kd);
-            } else {
-                ticks_to(t_end, true);
-            }
-        }
+        ticks_upto(t_end, true);
         const uint32_t n_ticks = tau - tau0;
-        k.app += kd.app;
-        k.drop += kd.drop;
 
-        // ---- every other sender saw the same ticks and heard the announcement and d's data
-        //      (simple_stack.py:130-157: += p at the start, += -p at the end of each transmission) ---------
-        st.qb[oq + (uint32_t)d] = (uint8_t)len_d;
-        for (int j = 0; j < D; ++j) {
-            if (j == d) continue;
-            const uint32_t l0 = st.qb[oq + (uint32_t)j];
-            st.qb[oq + (uint32_t)j] = (uint8_t)gw_len_after_ticks(l0, n_ticks, (uint32_t)c.mult[j], k);
-            const double a0 = st.rxp[(size_t)j * N + e];
-            const double pa = gw_link<PER_ENV>(st, R, RRM, j, e);
-            double a = (a0 + pa) + (-pa);
-            if (n_data) {
-                const double pd = gw_link<PER_ENV>(st, R, d, j, e);
-                for (int n = 0; n < n_data; ++n) {
-                    const double b = (a + pd) + (-pd);
-                    if (b == a) break;                                    // a fixed point of the (+p, -p) pair stays one
-                    a = b;
+        // ---- queue lengths of every sender (all tick together) -----------------------------------------------
+        if (PACKED) {
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                GwTally ki = {0, 0, 0, 0, 0};
+                const uint32_t li = gw_len_after_ticks(nb[i], n_ticks, (uint32_t)c.mult[i], ki);   // (i compile-time)
+                nb[i] = (i == d) ? len_d : li;
+            }
+#pragma unroll
+            for (int w = 0; w < NWC; ++w) {
+                const int b = 16 * w;
+                uint4 o;
+                o.x = nb[b + 0] | (nb[b + 1] << 8) | (nb[b + 2] << 16) | (nb[b + 3] << 24);
+                o.y = nb[b + 4] | (nb[b + 5] << 8) | (nb[b + 6] << 16) | (nb[b + 7] << 24);
+                o.z = nb[b + 8] | (nb[b + 9] << 8) | (nb[b + 10] << 16) | (nb[b + 11] << 24);
+                o.w = nb[b + 12] | (nb[b + 13] << 8) | (nb[b + 14] << 16) | (nb[b + 15] << 24);
+                st_(st.qb, oq + 16u * w, o);
+            }
+        } else {
+            GwTally ki = {0, 0, 0, 0, 0};
+            for (int i = 0; i < D; ++i)
+                if (i != d) st.qb[oq + (uint32_t)i] = (uint8_t)gw_len_after_ticks(st.qb[oq + (uint32_t)i], n_ticks, (uint32_t)cp->mult[i], ki);
+            st.qb[oq + (uint32_t)d] = (uint8_t)len_d;
+        }
+
+        // ---- all-pairs, D <= 6 (rows in registers) and the any-D path (in memory) -------------------------------
+        if (ROWS) {
+            double rn[2 * NH];
+#pragma unroll
+            for (int j = 0; j < 2 * NH; ++j) rn[j] = half_of(rxv[j >> 1], j & 1);
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const double pa = PER_ENV ? half_of(pav[j >> 1], j & 1) : s_prx[RRM * R + j];
+                const double pd = PER_ENV ? half_of(pdv[j >> 1], j & 1) : s_prx[d * R + j];
+                const double a = heard(rn[j], pa, pd, n_data);
+                if (j != d && !(a >= 0.0)) fl |= GW_FLAG_REFEXC;
+                rn[j] = (j == d) ? rx_d : a;
+            }
+            rn[RRM] = rx_r;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) st_(st.rxp, orx + 16u * h, make_double2(rn[2 * h], rn[2 * h + 1]));
+        } else {
+            st.rxp[(size_t)e * RP + d] = rx_d;
+            if (rx_r != rx_r0) st.rxp[(size_t)e * RP + RRM] = rx_r;
+            if (!COOP) {
+                for (int j = 0; j < D; ++j) {
+                    if (j == d) continue;
+                    const double a0 = st.rxp[(size_t)e * RP + j];
+                    const double a = heard(a0, link(RRM, j), link(d, j), n_data);
+                    if (!(a >= 0.0)) fl |= GW_FLAG_REFEXC;
+                    if (a != a0) st.rxp[(size_t)e * RP + j] = a;
                 }
             }
-            if (!(a >= 0.0)) fl |= GW_FLAG_REFEXC;
-            if (a != a0) st.rxp[(size_t)j * N + e] = a;
+        }
+        if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + d) * 16u, ca);
+        if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + D + d) * 16u, cx);
+        if (st.talk) {                                                    // whose attenuation models exist now (Position.set asks)
+            const uint64_t t_new = (1ull << RRM) | (n_data ? (1ull << d) : 0ull);
+            const uint64_t t_old = st.talk[e];
+            if ((t_old | t_new) != t_old) st.talk[e] = t_old | t_new;
         }
 
         // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------------------
@@ -215,33 +382,64 @@ __global__ __launch_bounds__(256) void ct_step_dyn_kernel(GwState st, GwDevConst
         int32_t r = last_abs - abs_d;
         last_abs = abs_d;
         r = r > 10 ? 10 : (r < -10 ? -10 : r);
-        obs[e] = latest + c.counter_bound;
-        reward[e] = (float)r;
-        done[e] = (uint8_t)dn;
-
+        st_(obs, (size_t)e << 2, (int32_t)(latest + c.counter_bound));
+        st_(reward, (size_t)e << 2, (float)r);
+        st_(done, (size_t)e, (uint8_t)dn);
         st_(st.tw, o16, make_double2(t_end, wake));
         st_(st.tk, o16, make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31)));
     }
-    publish_env_counters(st.sa, N, e, k.pop, k.deliv, k_bad, fl, 1u);
+    if (live) publish_env_counters(st.sa, N, e, k_pop, k_deliv, k_bad, fl, 1u);
+
+    // ---- all-pairs, D = 8 / 16 / 32: groups of D lanes, one lane per listening radio ------------------------------
+    if (COOP) {
+        constexpr int G = DT > 0 ? DT : 64;                       // lanes per env
+        constexpr int EPP = 64 / G;                               // envs per pass
+        const int lane = threadIdx.x;
+        const int j = lane % G;                                   // this lane's radio
+        const int act = (live && !bad) ? 1 : 0;
+        // (the walking lane's own two stores above -- rx[d], rx[RRM] -- touch other words than the listeners' here)
+#pragma unroll 1
+        for (int q = 0; q < G; ++q) {
+            const int src = q * EPP + lane / G;                   // the lane that walked this group's env
+            const int dd = __shfl(d, src);
+            const int nn = __shfl(n_data, src);
+            const int on = __shfl(act, src);
+            const uint32_t eq = blockIdx.x * 64u + (uint32_t)src;
+            uint32_t flj = 0;
+            if (on && j != dd) {
+                const size_t row = (size_t)eq * RP;
+                const double a0 = st.rxp[row + j];
+                const double pa = PER_ENV ? st.prx_env[((size_t)eq * R + RRM) * RP + j] : s_prx[RRM * R + j];
+                const double pd = (nn == 0) ? 0.0 : (PER_ENV ? st.prx_env[((size_t)eq * R + dd) * RP + j] : s_prx[dd * R + j]);
+                const double a = heard(a0, pa, pd, nn);
+                if (!(a >= 0.0)) flj = GW_FLAG_REFEXC;
+                if (a != a0) st_(st.rxp, (row + j) * 8u, a);
+            }
+            // "the reference would raise" of any listener of the env: OR across the group, one atomic by its first lane
+#pragma unroll
+            for (int o = G >> 1; o > 0; o >>= 1) flj |= (uint32_t)__shfl_xor((int)flj, o);
+            if (j == 0 && flj) __hip_atomic_fetch_or(st.sa + (size_t)3 * N + eq, flj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // FsplAttenuation._update + dbmToMilliwatts with the device libm (devices/core.py:88-95, attenuation_models.py:28-36,
-// simple_stack.py:111); co-located radios keep attenuation 0
-__device__ __forceinline__ double link_power(double ax, double ay, double bx, double by, double extra_db, double tx_dbm,
-                                             double twenty_log_f)
+// simple_stack.py:111); a model created for a pair on one spot starts (and stays) at 0 dB
+__device__ __forceinline__ double link_power(double dist, double extra_db, double tx_dbm, double twenty_log_f, bool same)
 {
-    double att = 0.0;
-    if (!(ax == bx && ay == by)) {
-        const double dist = sqrt(pow(ax - bx, 2.0) + pow(ay - by, 2.0));
-        att = 20 * log10(dist) + twenty_log_f - 147.55;
-    }
+    double att = same ? 0.0 : 20 * log10(dist) + twenty_log_f - 147.55;
     if (extra_db != 0.0) att = (0.0 + att) + extra_db;                    // joined model: sum([fspl, custom])
     return pow(10.0, (tx_dbm - att) / 10);
 }
 
-// Position.set on radio `radio` (or on every radio when radio < 0) of the envs selected by mask, then the attenuation
-// models of every link of a moved radio recompute (devices/core.py:77-86 -> physical.py:380-386).  Nothing is on the
-// air between two env.step() calls, so no reception is re-integrated (simple_stack.py:119-128 acts on active ones only).
+// Position.set on radio `radio` (or, radio < 0, on every radio in index order: successive Position.set calls) of the envs
+// selected by mask.  Each set notifies the attenuation models of the moved radio's pairs (devices/core.py:77-86 ->
+// physical.py:380-386), which -- as in the reference --
+//   * do not update while the pair is >= STANDBY_THRESHOLD = 3000 m apart (physical.py:371-386: the stale value stays),
+//   * do not update when the pair now shares one spot (FsplAttenuation._update returns early, attenuation_models.py:31-33),
+//   * do not exist before one of the two radios has transmitted (models are created at first use, physical.py:500-528;
+//     GwState::talk): such a pair has nothing to keep and takes the positions of the moment.
+// Nothing is on the air between two env.step() calls, so no reception is re-integrated (simple_stack.py:119-128).
 __global__ void ct_set_position_kernel(GwState st, GwDevConst c, int radio, const double* __restrict__ xs,
                                        const double* __restrict__ ys, const double* __restrict__ all_pos,
                                        const uint8_t* __restrict__ mask)
@@ -250,26 +448,33 @@ __global__ void ct_set_position_kernel(GwState st, GwDevConst c, int radio, cons
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     if (mask && !mask[e]) return;
-    const int R = c.D + 1;
-    if (radio >= 0) {
-        st.pos_env[((size_t)radio * 2 + 0) * N + e] = xs[e];
-        st.pos_env[((size_t)radio * 2 + 1) * N + e] = ys[e];
-    } else {
-        for (int r = 0; r < R; ++r) {
-            st.pos_env[((size_t)r * 2 + 0) * N + e] = all_pos[((size_t)e * R + r) * 2 + 0];
-            st.pos_env[((size_t)r * 2 + 1) * N + e] = all_pos[((size_t)e * R + r) * 2 + 1];
-        }
-    }
-    for (int a = 0; a < R; ++a) {
-        if (radio >= 0 && a != radio) continue;
-        const double ax = st.pos_env[((size_t)a * 2 + 0) * N + e], ay = st.pos_env[((size_t)a * 2 + 1) * N + e];
+    const int D = c.D, R = D + 1, RP = gw_rp(R);
+    double* pos = st.pos_env + (size_t)e * R * 2;
+    double* prx = st.prx_env + (size_t)e * R * RP;
+    const uint64_t talk = st.talk[e];
+    const int a_lo = radio >= 0 ? radio : 0, a_hi = radio >= 0 ? radio + 1 : R;
+    bool moved_any = false;
+    for (int a = a_lo; a < a_hi; ++a) {
+        const double ax = radio >= 0 ? xs[e] : all_pos[((size_t)e * R + a) * 2 + 0];
+        const double ay = radio >= 0 ? ys[e] : all_pos[((size_t)e * R + a) * 2 + 1];
+        pos[a * 2 + 0] = ax;
+        pos[a * 2 + 1] = ay;
         for (int b = 0; b < R; ++b) {
             if (b == a) continue;
-            const double bx = st.pos_env[((size_t)b * 2 + 0) * N + e], by = st.pos_env[((size_t)b * 2 + 1) * N + e];
-            const double p = link_power(ax, ay, bx, by, st.extra_tab[a * R + b], c.tx_power_dbm, c.twenty_log_f);
-            st.prx_env[((size_t)(a * R + b)) * N + e] = p;               // symmetric: attenuation depends on the pair only
-            st.prx_env[((size_t)(b * R + a)) * N + e] = p;
+            const double bx = pos[b * 2 + 0], by = pos[b * 2 + 1];
+            const bool same = ax == bx && ay == by;
+            const double dist = sqrt(pow(ax - bx, 2.0) + pow(ay - by, 2.0));
+            const bool exists = (((talk >> a) | (talk >> b)) & 1ull) != 0;
+            if (exists && (same || dist >= 3000.0)) continue;             // the stale attenuation stays
+            const double p = link_power(dist, st.extra_tab[a * R + b], c.tx_power_dbm, c.twenty_log_f, same);
+            prx[a * RP + b] = p;                                          // symmetric: attenuation depends on the pair only
+            prx[b * RP + a] = p;
+            moved_any = true;
         }
+    }
+    if (moved_any && st.bcache) {                                         // signal powers changed: the BER cache's keys no longer say enough
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int i = 0; i < 2 * D; ++i) st.bcache[((size_t)e * 2 * D + i) * 2] = nan;
     }
 }
 
@@ -280,28 +485,50 @@ __global__ void ct_init_dyn_kernel(GwState st, GwDevConst c, double thermal)
     const uint32_t N = (uint32_t)st.N;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
-    const int R = c.D + 1;
-    for (int r = 0; r < R; ++r) st.rxp[(size_t)r * N + e] = thermal;
+    const int D = c.D, R = D + 1, RP = gw_rp(R);
+    for (int r = 0; r < RP; ++r) st.rxp[(size_t)e * RP + r] = r < R ? thermal : 0.0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    if (st.bcache)
+        for (int i = 0; i < 2 * D; ++i) { st.bcache[((size_t)e * 2 * D + i) * 2] = nan; st.bcache[((size_t)e * 2 * D + i) * 2 + 1] = 0.0; }
+    if (st.talk) st.talk[e] = 0ull;
     if (st.prx_env) {
-        for (int i = 0; i < R * R; ++i) st.prx_env[(size_t)i * N + e] = st.prx_tab[i];
-        for (int i = 0; i < R * 2; ++i) st.pos_env[(size_t)i * N + e] = st.pos_tab[i];
+        for (int a = 0; a < R; ++a)
+            for (int b = 0; b < RP; ++b) st.prx_env[((size_t)e * R + a) * RP + b] = b < R ? st.prx_tab[a * R + b] : 0.0;
+        for (int i = 0; i < R * 2; ++i) st.pos_env[(size_t)e * R * 2 + i] = st.pos_tab[i];
     }
 }
 
 inline int ok_or_ehip() { return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP; }
+
+template <int DT>
+int launch_live(const GwState& st, const int32_t* device, const int32_t* duration, int32_t* obs, float* reward, uint8_t* done,
+                hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((st.N + 63) / 64);
+    if (st.prx_env)
+        hipLaunchKernelGGL((ct_step_live_kernel<DT, true>), dim3(grid), dim3(64), 0, stream, GW_LEAD_ARGS(st), obs, reward, done);
+    else
+        hipLaunchKernelGGL((ct_step_live_kernel<DT, false>), dim3(grid), dim3(64), 0, stream, GW_LEAD_ARGS(st), obs, reward, done);
+    return ok_or_ehip();
+}
 
 } // namespace
 
 int gw_launch_step_dyn(const GwState& st, const GwDevConst& cst, const int32_t* device, const int32_t* duration,
                        int32_t* obs, float* reward, uint8_t* done, void* stream)
 {
-    const unsigned blk = 64;
-    const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
-    if (st.prx_env)
-        hipLaunchKernelGGL(ct_step_dyn_kernel<true>, dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
-    else
-        hipLaunchKernelGGL(ct_step_dyn_kernel<false>, dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, device, duration, obs, reward, done);
-    return ok_or_ehip();
+    (void)cst;
+    hipStream_t s = (hipStream_t)stream;
+    switch (st.D) {
+    case 2:  return launch_live<2>(st, device, duration, obs, reward, done, s);
+    case 3:  return launch_live<3>(st, device, duration, obs, reward, done, s);
+    case 4:  return launch_live<4>(st, device, duration, obs, reward, done, s);
+    case 6:  return launch_live<6>(st, device, duration, obs, reward, done, s);
+    case 8:  return launch_live<8>(st, device, duration, obs, reward, done, s);
+    case 16: return launch_live<16>(st, device, duration, obs, reward, done, s);
+    case 32: return launch_live<32>(st, device, duration, obs, reward, done, s);
+    default: return launch_live<0>(st, device, duration, obs, reward, done, s);
+    }
 }
 
 int gw_launch_init_dyn(const GwState& st, const GwDevConst& cst, double thermal, void* stream)

@@ -571,49 +571,7 @@ __device__ __forceinline__ void ct_step_sfx_body(const GwState& st, const GwDevC
     STAMP(12);
 }
 
-// The kernel's arguments: only what changes per call and the addresses of the wave's first loads -- under 100 bytes.
-// Everything else (the handle's GwDevConst and GwState, the tables) sits in the header of the `ip` allocation
-// (gw_internal.h: gw_blob_header) and is read from there by scalar loads.
-//  * As leading scalar arguments the seven values below are PRELOADED into SGPRs by the command processor
-//    (-amdgpu-kernarg-preload-count, Makefile; 14 dwords at most), so the table and state loads issue in the wave's first
-//    cycles; read from a GwState in the kernel-argument segment they cost two scalar-cache round trips before the first
-//    vector load could leave.  The constants are fetched under the shadow of those loads.
-//  * On the host, a launch with both structs by value (1.2 KB) spent 3.6 us of its 5.5 us writing arguments into
-//    device-visible memory (tools/launch_floor.hip); the short block takes env.step()'s enqueue below the kernel's time
-//    in every phase.
-#define GW_LEAD_PARAMS uint32_t* __restrict__ ip, double* __restrict__ tw, uint32_t* __restrict__ tk, uint8_t* __restrict__ qb, \
-                       const int32_t* __restrict__ device, const int32_t* __restrict__ duration, uint32_t n_envs, uint32_t dev_stage
-// dev_stage: sender count | chunks of the tables to stage << 8 (one argument: the preload window holds 14 dwords)
-#define GW_LEAD_ARGS(st_) (st_).ip, (st_).tw, (st_).tk, (st_).qb, device, duration, (uint32_t)(st_).N, \
-                          ((uint32_t)(st_).D | ((uint32_t)(st_).stage_chunks << 8))
-// (read through the CONSTANT address space: nothing writes the header while a step kernel runs, and as constant-space
-//  loads the reads become scalar loads that the compiler may issue anywhere -- in particular at the top of the wave,
-//  in front of the fence that follows the table staging; as plain global loads they stayed behind that fence and their
-//  latency was exposed after the tables had landed)
-// (the host pass of the compiler parses these device functions too and has no address spaces: plain types there)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GW_AS_CONST __attribute__((address_space(4)))
-#else
-#define GW_AS_CONST
-#endif
-template <int DT>
-__device__ __forceinline__ GwDevConst hdr_const(const uint32_t* ip, int n_dev)
-{
-    const int D = DT > 0 ? DT : n_dev;
-    const uint8_t* at = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(D) + gw_hdr_cst_off(D);
-    return *(const GW_AS_CONST GwDevConst*)at;                                   // (only the fields the body uses are loaded)
-}
-template <int DT>
-__device__ __forceinline__ GwState hdr_state(uint32_t* ip, double* tw, uint32_t* tk, uint8_t* qb, uint32_t n_envs, int n_dev)
-{
-    const int D = DT > 0 ? DT : n_dev;
-    const uint8_t* base = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(D);
-    GwState st = *(const GW_AS_CONST GwState*)(base + gw_hdr_st_off(D));
-    st.ip = ip; st.tw = tw; st.tk = tk; st.qb = qb; st.N = (int64_t)n_envs; st.D = D;
-    st.blob = base;
-    return st;
-}
-
+// (kernel arguments and the header in front of the `ip` records: GW_LEAD_PARAMS, hdr_state, hdr_const in ct_common.hip.h)
 template <int DT, int MODE>
 __global__ __launch_bounds__(64) void ct_step_sfx_kernel(GW_LEAD_PARAMS, int32_t* __restrict__ obs, float* __restrict__ reward,
                                                         uint8_t* __restrict__ done, uint8_t* __restrict__ fb)

@@ -450,8 +450,10 @@ int gw_create(const gw_config* cfg, gw_env** out)
     }
     double *d_prx = nullptr, *d_pos = nullptr, *d_extra = nullptr;
     if (env->dyn) {
-        TRY_ALLOC(st.rxp, N * R);  TRY_ALLOC(d_prx, R * R);  TRY_ALLOC(d_pos, R * 2);  TRY_ALLOC(d_extra, R * R);
-        if (per_env_geo) { TRY_ALLOC(st.prx_env, N * R * R);  TRY_ALLOC(st.pos_env, N * R * 2); }
+        const int RP = gw_rp(R);                            // rows of one env's radios, 16-byte aligned (gw_internal.h)
+        TRY_ALLOC(st.rxp, N * RP);  TRY_ALLOC(d_prx, R * R);  TRY_ALLOC(d_pos, R * 2);  TRY_ALLOC(d_extra, R * R);
+        if (!explicit_q) TRY_ALLOC(st.bcache, N * 2 * D * 2);
+        if (per_env_geo) { TRY_ALLOC(st.prx_env, N * R * RP);  TRY_ALLOC(st.pos_env, N * R * 2);  TRY_ALLOC(st.talk, N); }
         st.prx_tab = d_prx; st.pos_tab = d_pos; st.extra_tab = d_extra;
     }
     if (explicit_q) TRY_ALLOC(st.flags, N);
@@ -964,6 +966,23 @@ int gw_selftest_runq(uint64_t seed, int32_t operations, int32_t mult, int32_t co
     return (int)bad;
 }
 
+// per-env positions [N][R][2] / link powers [N][R][R] (from -> to) of a GW_CFG_PER_ENV_GEOMETRY handle, logical layout
+static int read_geometry(const GwState& st, bool positions, void* dst, size_t bytes, const char* field)
+{
+    const int64_t N = st.N;
+    const int R = st.R, RP = gw_rp(R);
+    const int per = positions ? R * 2 : R * R;
+    if (bytes != (size_t)N * per * sizeof(double))
+        return fail(GW_EFIELD, "field %s needs %zu bytes, got %zu", field, (size_t)N * per * sizeof(double), bytes);
+    double* o = (double*)dst;
+    if (positions) { HIP_TRY(hipMemcpy(o, st.pos_env, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
+    std::vector<double> v((size_t)N * R * RP);
+    HIP_TRY(hipMemcpy(v.data(), st.prx_env, v.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t e = 0; e < N; ++e)
+        for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b) o[(e * R + a) * R + b] = v[((size_t)e * R + a) * RP + b];
+    return GW_OK;
+}
+
 int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
 {
     if (!env || !field || !dst) return fail(GW_EINVAL, "env/field/dst is NULL");
@@ -1040,10 +1059,11 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         }
         if (!strcmp(field, "rx_power")) {
             NEED(N * R, double); double* o = (double*)dst;
-            if (st.rxp) {                            // live-PHY mode: the f64 itself, [R][N] on the device
-                std::vector<double> rx((size_t)N * R);
+            if (st.rxp) {                            // live-PHY mode: the f64 itself, rows of gw_rp(R) doubles per env
+                const int RP = gw_rp(R);
+                std::vector<double> rx((size_t)N * RP);
                 HIP_TRY(hipMemcpy(rx.data(), st.rxp, rx.size() * sizeof(double), hipMemcpyDeviceToHost));
-                for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = rx[(size_t)r * N + e];
+                for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = rx[(size_t)e * RP + r];
                 return GW_OK;
             }
             for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = env->tab.state_val[r][qb[(size_t)e * RB + D + r]];
@@ -1051,12 +1071,7 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         }
         if (!strcmp(field, "pos") || !strcmp(field, "link_power")) {
             if (!st.prx_env) return fail(GW_EFIELD, "field %s needs GW_CFG_PER_ENV_GEOMETRY", field);
-            const int per = field[0] == 'p' ? R * 2 : R * R;
-            NEED(N * per, double); double* o = (double*)dst;
-            std::vector<double> v((size_t)N * per);
-            HIP_TRY(hipMemcpy(v.data(), field[0] == 'p' ? st.pos_env : st.prx_env, v.size() * sizeof(double), hipMemcpyDeviceToHost));
-            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < per; ++i) o[e * per + i] = v[(size_t)i * N + e];
-            return GW_OK;
+            return read_geometry(st, field[0] == 'p', dst, bytes, field);
         }
         if (!strcmp(field, "queue")) {
             NEED(N * D * GW_QUEUE_CAP, uint32_t);
@@ -1148,18 +1163,14 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
     }
     if (!strcmp(field, "pos") || !strcmp(field, "link_power")) {
         if (!st.prx_env) return fail(GW_EFIELD, "field %s needs GW_CFG_PER_ENV_GEOMETRY", field);
-        const int per = field[0] == 'p' ? R * 2 : R * R;
-        NEED(N * per, double); double* o = (double*)dst;
-        std::vector<double> v((size_t)N * per);
-        HIP_TRY(hipMemcpy(v.data(), field[0] == 'p' ? st.pos_env : st.prx_env, v.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (int64_t e = 0; e < N; ++e) for (int i = 0; i < per; ++i) o[e * per + i] = v[(size_t)i * N + e];
-        return GW_OK;
+        return read_geometry(st, field[0] == 'p', dst, bytes, field);
     }
-    if (!strcmp(field, "rx_power") && st.rxp) {          // live-PHY mode: the f64 itself, [R][N] on the device
+    if (!strcmp(field, "rx_power") && st.rxp) {          // live-PHY mode: the f64 itself, rows of gw_rp(R) doubles per env
         NEED(N * R, double); double* o = (double*)dst;
-        std::vector<double> rx((size_t)N * R);
+        const int RP = gw_rp(R);
+        std::vector<double> rx((size_t)N * RP);
         HIP_TRY(hipMemcpy(rx.data(), st.rxp, rx.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = rx[(size_t)r * N + e];
+        for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = rx[(size_t)e * RP + r];
         return GW_OK;
     }
     if (!strcmp(field, "rx_power")) {

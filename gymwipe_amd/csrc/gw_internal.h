@@ -90,14 +90,26 @@ struct GwState {
     const double*     ber2;      // [2][D][S]
     const uint8_t*    cls2;      // [2][D][S]
     const uint8_t*    blob;      // GwBlobLayout: the default step kernel's tables in one block
-    // live-PHY mode (ct_step_dyn.hip): f64 received power per radio instead of the noise-state bytes
-    double*   rxp;        // [R][N]     phy._receivedPower, or nullptr (default mode)
+    // live-PHY mode (ct_step_dyn.hip): f64 received power per radio instead of the noise-state bytes.  One env's radios are
+    // CONTIGUOUS (rows of RP = gw_rp(R) doubles, 16-byte aligned): the all-pairs update of a step touches every radio of an
+    // env and one or two rows of its link matrix, so whole rows are what a lane -- or, for D >= 8, a group of D lanes -- reads.
+    double*   rxp;        // [N][RP]    phy._receivedPower, or nullptr (default mode)
     const double* prx_tab;   // [R][R]  link power from -> to, mW (host glibc tables)
     const double* pos_tab;   // [R][2]  the handle's geometry
     const double* extra_tab; // [R][R]  custom attenuation per pair, dB
-    double*   prx_env;    // [R][R][N]  per-env link powers (GW_CFG_PER_ENV_GEOMETRY), else nullptr
-    double*   pos_env;    // [R][2][N]  per-env positions
+    double*   prx_env;    // [N][R][RP] per-env link powers, row = talker (GW_CFG_PER_ENV_GEOMETRY), else nullptr
+    double*   pos_env;    // [N][R][2]  per-env positions
+    double*   bcache;     // [N][2D][2] {noise power, BER} last evaluated for: sender i hearing the RRM (entry i), the RRM
+                          //            hearing sender i (entry D + i); key NaN = empty.  BpskMcs.calculateBitErrorRate is two
+                          //            log10, three pow and a sqrt in f64 (physical.py:25-58,208-212): ~350 instructions that
+                          //            a step would otherwise spend twice; received powers settle on a few residue values.
+    uint64_t* talk;       // [N]        bit r: radio r has transmitted, i.e. its attenuation models exist (physical.py:500-528
+                          //            creates a pair's model at first use) -- what Position.set's keep-stale rules ask
 };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+constexpr int gw_rp(int R) { return (R + 1) & ~1; }        // doubles per row of rxp / prx_env
 
 // byte offsets inside GwState::blob (the default step kernel's tables; see ct_step_sfx.hip)
 struct GwBlobLayout {

@@ -69,7 +69,7 @@ struct cto_vec {
     uint64_t* n_app;      /* [n] queue appends                      */
     uint64_t* n_pop;      /* [n] queue pops                         */
     uint64_t* n_drop;     /* [n] drop-oldest events                 */
-    uint32_t* talked;     /* [n] bit r: radio r has transmitted, i.e. its attenuation models towards every other radio exist
+    uint64_t* talked;     /* [n] bit r: radio r has transmitted, i.e. its attenuation models towards every other radio exist
                            *     (AttenuationModelFactory.getInstance creates a pair's model at its first use, physical.py:500-528) */
 };
 
@@ -196,7 +196,7 @@ int cto_set_position(cto_vec* v, int radio, double x, double y)
         const double bx = v->cfg.pos[b][0], by = v->cfg.pos[b][1];
         const int same = (x == bx && y == by);
         const double dist = sqrt(pow(x - bx, 2.0) + pow(y - by, 2.0));    /* devices/core.py:88-95 */
-        const uint32_t pair = (1u << radio) | (1u << b);
+        const uint64_t pair = ((uint64_t)1 << radio) | ((uint64_t)1 << b);
         int exists = (v->talked[0] & pair) != 0;
         if (same || dist >= 3000.0) {
             for (int64_t e = 1; e < v->n; ++e)
@@ -363,7 +363,7 @@ static void step_one(cto_vec* v, int64_t e, int d, int duration,
     int L = ndigits(slots);
     txtimes an = tx_times(v, t_a, mh, L);
     v->n_tx[e]++;
-    v->talked[e] |= 1u << RRM;                               /* every listener's model towards the RRM exists from here on */
+    v->talked[e] |= (uint64_t)1 << RRM;                               /* every listener's model towards the RRM exists from here on */
     for (int j = 0; j < D; ++j) rx[j] = rx[j] + v->prx[RRM][j];       /* :130-139 */
     int granted = receive(&c, d, v->prx[RRM][d], &an, mh, L);
     for (int j = 0; j < D; ++j) rx[j] = rx[j] + (-v->prx[RRM][j]);    /* :146-154 */
@@ -393,7 +393,7 @@ static void step_one(cto_vec* v, int64_t e, int d, int duration,
             v->n_pop[e]++;
             txtimes x = tx_times(v, cur, mh, (int)s - mh);
             v->n_tx[e]++;
-            v->talked[e] |= 1u << d;
+            v->talked[e] |= (uint64_t)1 << d;
             for (int j = 0; j < R; ++j) if (j != d) rx[j] = rx[j] + v->prx[d][j];
             int ok = receive(&c, RRM, v->prx[d][RRM], &x, mh, (int)s - mh);
             for (int j = 0; j < R; ++j) if (j != d) rx[j] = rx[j] + (-v->prx[d][j]);

@@ -397,3 +397,116 @@ def test_per_env_geometry_with_the_generic_kernel():
         assert (a.view(np.uint8) == b.view(np.uint8)).all(), f
     a, b = env.get_state("rx_power"), np.concatenate([o.get("rx_power") for o in orcs])
     assert np.max(np.abs(a - b) / b) < 1e-5
+
+
+# ---- BASELINE's stress shape with per-env geometry: 16 devices x 65 536 envs -------------------------------------------------
+@pytest.mark.gpu
+def test_per_env_geometry_at_full_size_d16():
+    """65 536 envs x 16 devices, every env with its own positions (64 layouts dealt round-robin: one oracle handle of 1 024
+    envs per layout), the all-pairs part done by groups of 16 lanes.  Moves between steps included.  Integers, flags and
+    clocks bit-exact, received powers within 1e-5 (link powers come from the device libm)."""
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv
+    from oracle.ct_oracle import CtOracle, default_config
+    N, D, K, L = 65536, 16, 24, 64
+    R = D + 1
+    rng = np.random.default_rng(2024)
+    lay = np.zeros((L, R, 2))
+    ang, rad = rng.uniform(0, 2 * np.pi, (L, D)), rng.uniform(0.6, 3.2, (L, D))
+    lay[:, :D, 0], lay[:, :D, 1] = rad * np.cos(ang), rad * np.sin(ang)
+    lay[:, D] = rng.uniform(-0.3, 0.3, (L, 2))
+    grp = np.arange(N) % L
+    env = VecCounterTrafficEnv(N, num_devices=D, per_env_geometry=True)
+    env.set_positions(lay[grp])
+    orcs = [CtOracle(N // L, D, config=default_config(D, positions=[tuple(p) for p in lay[l, :D]], rrm_pos=tuple(lay[l, D])), nthreads=8)
+            for l in range(L)]
+    dev, dur = action_stream(99, K, N, D)
+    assert (env.reset().cpu().numpy() == 65536).all()
+    for o in orcs:
+        o.reset()
+    for k in range(K):
+        if k in (9, 17):                                          # Position.set on a sender / on the RRM, new spot per layout
+            r = 5 if k == 9 else D
+            nx, ny = rng.uniform(-3, 3, L), rng.uniform(-3, 3, L)
+            env.set_position(r, nx[grp], ny[grp])
+            for l, o in enumerate(orcs):
+                o.set_position(r, nx[l], ny[l])
+        o_, r_, d_, _ = env.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+        o_, r_ = o_.cpu().numpy(), r_.cpu().numpy()
+        for l, o in enumerate(orcs):
+            wo, wr, wd = o.step(dev[k][l::L], dur[k][l::L])
+            assert (o_[l::L] == wo).all() and (r_[l::L] == wr).all(), (k, l)
+    for f in INT_FIELDS + ("now", "wake"):
+        a = env.get_state(f)
+        for l, o in enumerate(orcs):
+            assert (np.ascontiguousarray(a[l::L]).view(np.uint8) == o.get(f).view(np.uint8)).all(), (f, l)
+    a = env.get_state("rx_power")
+    for l, o in enumerate(orcs):
+        b = o.get("rx_power")
+        assert np.max(np.abs(a[l::L] - b) / b) < 1e-5, l
+    assert int(env.get_state("n_delivered").sum()) > 0
+    env.check()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [3, 8])
+def test_moves_past_standby_and_onto_other_radios_on_the_gpu(D):
+    """The keep-the-stale-attenuation rules of Position.set (>= 3000 m apart; onto another radio's spot; models that do not
+    exist yet) through gw_set_position / gw_set_positions, one oracle handle per env (pinned to layer 1 on the CPU above)."""
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv
+    from oracle.ct_oracle import CtOracle, default_config
+    N, K = 96, 50
+    R = D + 1
+    rng = np.random.default_rng(31 + D)
+    pos = np.zeros((N, R, 2))
+    pos[:, :D] = rng.uniform(-3, 3, (N, D, 2))
+    pos[:, D] = rng.uniform(-0.4, 0.4, (N, 2))
+    env = VecCounterTrafficEnv(N, num_devices=D, per_env_geometry=True)
+    env.set_positions(pos)
+    orcs = [CtOracle(1, D, config=default_config(D, positions=[tuple(p) for p in pos[e, :D]], rrm_pos=tuple(pos[e, D]))) for e in range(N)]
+    cur = pos.copy()
+    dev, dur = action_stream(8, K, N, D)
+    env.reset()
+    for o in orcs:
+        o.reset()
+    for k in range(K):
+        if k in (0, 1, 2, 7, 13, 21, 30, 41):                      # (the first ones before most models exist)
+            r = int(rng.integers(0, R))
+            kind = rng.integers(0, 4, N)                           # near / far / onto another radio / back home
+            other = (r + 1 + rng.integers(0, R - 1, N)) % R
+            x = np.where(kind == 0, rng.uniform(-4, 4, N), np.where(kind == 1, rng.choice([-1.0, 1.0], N) * rng.uniform(3100, 9000, N),
+                         np.where(kind == 2, cur[np.arange(N), other, 0], pos[:, r, 0])))
+            y = np.where(kind == 0, rng.uniform(-4, 4, N), np.where(kind == 1, rng.uniform(-50, 50, N),
+                         np.where(kind == 2, cur[np.arange(N), other, 1], pos[:, r, 1])))
+            if k == 13:                                            # all radios at once (index order = successive Position.set calls)
+                newp = cur.copy()
+                newp[:, r, 0], newp[:, r, 1] = x, y
+                r2 = (r + 1) % R
+                newp[:, r2] = cur[:, r]                            # r2 goes where r just left
+                env.set_positions(newp)
+                for e, o in enumerate(orcs):
+                    for rr in range(R):
+                        o.set_position(rr, newp[e, rr, 0], newp[e, rr, 1])
+                cur = newp
+            else:
+                env.set_position(r, x, y)
+                for e, o in enumerate(orcs):
+                    o.set_position(r, x[e], y[e])
+                cur[:, r, 0], cur[:, r, 1] = x, y
+        o_, r_, d_, _ = env.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+        want = [orcs[e].step(dev[k, e:e + 1], dur[k, e:e + 1]) for e in range(N)]
+        assert (o_.cpu().numpy() == np.array([w[0][0] for w in want])).all() and (r_.cpu().numpy() == np.array([w[1][0] for w in want])).all(), k
+    lp = env.get_state("link_power")
+    for e in range(N):
+        for a in range(R):
+            for b in range(R):
+                if a != b:
+                    want = orcs[e].rx_power_mw(a, b)
+                    assert abs(lp[e, a, b] - want) <= 1e-9 * want, (e, a, b)
+    for f in ("counter", "qlen", "received", "last_abs", "now", "wake") + STAT_FIELDS:
+        a = env.get_state(f)
+        b = np.concatenate([o.get(f) for o in orcs])
+        assert (a.view(np.uint8) == b.view(np.uint8)).all(), f
+    fl_gpu, fl_orc = env.get_state("flags"), np.concatenate([o.get("flags") for o in orcs])
+    assert ((fl_gpu & 3) == (fl_orc & 3)).all()                  # negative noise powers (radios on one spot) flagged alike

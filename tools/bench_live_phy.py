@@ -8,13 +8,16 @@ import torch
 import gymwipe_amd
 from gymwipe_amd.actions import actions_torch
 
-N, D, K, W = int(os.environ.get("N", 65536)), 4, 256, 64
+N, D, K, W = int(os.environ.get("N", 65536)), int(os.environ.get("D", 4)), 256, 64
+MODES = os.environ.get("GW_BENCH_MODES", "suffix,explicit").split(",")
 dev, dur = actions_torch(7, 0, N, 0, W + K, D, device="cuda")
 rng = np.random.default_rng(3)
 pos = np.zeros((N, D + 1, 2))
 ang, rad = rng.uniform(0, 2 * np.pi, (N, D)), rng.uniform(1.0, 3.0, (N, D))
 pos[:, :D, 0], pos[:, :D, 1] = rad * np.cos(ang), rad * np.sin(ang)
 for name, kw in (("live PHY, per-env geometry, suffix queues", {}), ("live PHY, per-env geometry, explicit queues", {"explicit_queue": True})):
+    if ("explicit" if kw else "suffix") not in MODES:
+        continue
     env = gymwipe_amd.VecCounterTrafficEnv(N, D, per_env_geometry=True, **kw)
     env.set_positions(pos)
     def run(lo, hi):

@@ -66,7 +66,9 @@ __device__ __forceinline__ double ber_live(double sig_mw, double noise_mw, doubl
 // BER of a link at a noise power, through the link's one-entry cache {noise, ber}
 __device__ __forceinline__ double ber_cached(double2& entry, bool& dirty, double sig, double noise, double ten_log_br)
 {
+#ifndef GW_EXP_NO_BCACHE
     if (noise == entry.x) return entry.y;
+#endif
     entry.x = noise;
     entry.y = ber_live(sig, noise, ten_log_br);
     dirty = true;
@@ -120,6 +122,10 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
     if (!PER_ENV) {
         for (int i = threadIdx.x; i < R * R; i += 64) s_prx[i] = st.prx_tab[i];
     }
+    // {multiplicity, ceil(65536 / multiplicity)} per sender: looked up by the lane's action right after it arrives -- from LDS,
+    // not by a second global round trip
+    __shared__ uint2 s_mi[DT > 0 ? DT : GW_MAX_DEVICES];
+    for (int i = threadIdx.x; i < D; i += 64) s_mi[i] = make_uint2((uint32_t)cp->mult[i], cp->inv16[i]);
 
     // ---- loads, all issued before anything is waited for ---------------------------------------------------------------
     int d = device[el];
@@ -130,10 +136,14 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
     uint4 qw[NWC];
 #pragma unroll
     for (int w = 0; w < NWC; ++w) qw[w] = PACKED ? ld<uint4>(st.qb, oq + 16u * w) : make_uint4(0u, 0u, 0u, 0u);
-    double2 rxv[ROWS ? NH : 1], pav[ROWS && PER_ENV ? NH : 1];
+    double2 rxv[ROWS ? NH : 1], pav[ROWS && PER_ENV ? NH : 1], cav[ROWS ? DT : 1];
     if (ROWS) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) rxv[h] = ld<double2>(st.rxp, orx + 16u * h);
+        // all D "sender i hears the RRM" cache entries: which one the step needs depends on the action, and a load issued
+        // only once the action has arrived is a second memory round trip in front of the announcement's decision
+#pragma unroll
+        for (int i = 0; i < DT; ++i) cav[i] = ld<double2>(st.bcache, ((size_t)el * 2 * DT + i) * 16u);
         if (PER_ENV) {
 #pragma unroll
             for (int h = 0; h < NH; ++h) pav[h] = ld<double2>(st.prx_env, olk + ((size_t)RRM * RP) * 8u + 16u * h);
@@ -141,14 +151,21 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
     }
     asm volatile("" : "+v"(d), "+v"(du));
     asm volatile("" : "+v"(bp.x), "+v"(bp.y), "+v"(bp.z), "+v"(bp.w));
-    __syncthreads();                                             // s_prx
+    __syncthreads();                                             // s_prx, s_mi
 
     const bool bad = (unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration;
     const int dq = bad ? 0 : d;                                   // a valid index for the dependent loads below
     // dependent on the action: the two cache entries, the talker's row (its link to every listener) and, unless the rows
     // are in registers already, the four scalars of the two deciding receptions
-    double2 ca = ld<double2>(st.bcache, ((size_t)el * 2 * D + dq) * 16u);
-    double2 cx = ld<double2>(st.bcache, ((size_t)el * 2 * D + D + dq) * 16u);
+    double2 ca;
+    if (ROWS) {
+        ca = cav[0];
+#pragma unroll
+        for (int i = 1; i < DT; ++i) { ca.x = (i == dq) ? cav[i].x : ca.x; ca.y = (i == dq) ? cav[i].y : ca.y; }
+    } else {
+        ca = ld<double2>(st.bcache, ((size_t)el * 2 * D + dq) * 16u);
+    }
+    double2 cx = ld<double2>(st.bcache, ((size_t)el * 2 * D + D + dq) * 16u);   // (first needed at the first data packet)
     double2 pdv[ROWS && PER_ENV ? NH : 1];
     if (ROWS && PER_ENV) {
 #pragma unroll
@@ -166,15 +183,18 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             p_a = 0.0;
 #pragma unroll
             for (int j = 0; j < DT; ++j) p_a = (j == dq) ? half_of(pav[j >> 1], j & 1) : p_a;
-            p_x = half_of(pdv[RRM >> 1], RRM & 1);
         } else {
-            p_a = link(RRM, dq); p_x = link(dq, RRM);
+            p_a = link(RRM, dq);
         }
     } else {
         rx_d0 = st.rxp[(size_t)el * RP + dq];
         rx_r0 = st.rxp[(size_t)el * RP + RRM];
-        p_a = link(RRM, dq); p_x = link(dq, RRM);
+        p_a = link(RRM, dq);
     }
+    // the attenuation of a pair is one number (one model per unordered pair, physical.py:500-528; gw_create refuses an
+    // asymmetric extra_att_db) and every radio sends with the same power: the link matrix is symmetric bit for bit, so the
+    // RRM hears d with the power d hears the RRM with -- no load that waits for the action
+    p_x = p_a;
 
     const StepMath m(c);
     uint32_t rvm = tk0.z;                                         // (record layout: ct_step_sfx.hip)
@@ -209,7 +229,8 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         } else {
             len_d = st.qb[oq + (uint32_t)d];
         }
-        const uint32_t mult_d = (uint32_t)cp->mult[d], inv16_d = cp->inv16[d];
+        const uint2 mi_d = s_mi[d];
+        const uint32_t mult_d = mi_d.x, inv16_d = mi_d.y;
         const double t_a = tw0.x;
         double wake = tw0.y;
         const uint32_t tau0 = tk0.x, nbp = tk0.y;
@@ -321,7 +342,11 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
                 GwTally ki = {0, 0, 0, 0, 0};
                 const uint32_t li = gw_len_after_ticks(nb[i], n_ticks, (uint32_t)c.mult[i], ki);   // (i compile-time)
                 nb[i] = (i == d) ? len_d : li;
+                // bytes D .. 2D of the record (the default kernel's noise states, unused here): bit 0 = radio i has transmitted,
+                // i.e. its attenuation models exist (Position.set's keep-stale rules ask, ct_set_position_kernel)
+                nb[DT + i] |= (i == d && n_data) ? 1u : 0u;
             }
+            nb[2 * DT] |= 1u;                                             // the RRM has (the announcement)
 #pragma unroll
             for (int w = 0; w < NWC; ++w) {
                 const int b = 16 * w;
@@ -337,6 +362,8 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             for (int i = 0; i < D; ++i)
                 if (i != d) st.qb[oq + (uint32_t)i] = (uint8_t)gw_len_after_ticks(st.qb[oq + (uint32_t)i], n_ticks, (uint32_t)cp->mult[i], ki);
             st.qb[oq + (uint32_t)d] = (uint8_t)len_d;
+            if (n_data) st.qb[oq + (uint32_t)(D + d)] = 1;                // (talk bits, see above)
+            st.qb[oq + (uint32_t)(2 * D)] = 1;
         }
 
         // ---- all-pairs, D <= 6 (rows in registers) and the any-D path (in memory) -------------------------------
@@ -353,10 +380,12 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
                 rn[j] = (j == d) ? rx_d : a;
             }
             rn[RRM] = rx_r;
+            // (the residues settle on fixed points of the (+p, -p) pairs: most steps change nothing)
 #pragma unroll
-            for (int h = 0; h < NH; ++h) st_(st.rxp, orx + 16u * h, make_double2(rn[2 * h], rn[2 * h + 1]));
+            for (int h = 0; h < NH; ++h)
+                if (rn[2 * h] != rxv[h].x || rn[2 * h + 1] != rxv[h].y) st_(st.rxp, orx + 16u * h, make_double2(rn[2 * h], rn[2 * h + 1]));
         } else {
-            st.rxp[(size_t)e * RP + d] = rx_d;
+            if (rx_d != rx_d0) st.rxp[(size_t)e * RP + d] = rx_d;
             if (rx_r != rx_r0) st.rxp[(size_t)e * RP + RRM] = rx_r;
             if (!COOP) {
                 for (int j = 0; j < D; ++j) {
@@ -370,11 +399,6 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         }
         if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + d) * 16u, ca);
         if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + D + d) * 16u, cx);
-        if (st.talk) {                                                    // whose attenuation models exist now (Position.set asks)
-            const uint64_t t_new = (1ull << RRM) | (n_data ? (1ull << d) : 0ull);
-            const uint64_t t_old = st.talk[e];
-            if ((t_old | t_new) != t_old) st.talk[e] = t_old | t_new;
-        }
 
         // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------------------
         const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
@@ -398,27 +422,39 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         const int j = lane % G;                                   // this lane's radio
         const int act = (live && !bad) ? 1 : 0;
         // (the walking lane's own two stores above -- rx[d], rx[RRM] -- touch other words than the listeners' here)
+        constexpr int PQ = G >= 4 ? 4 : G;                        // passes whose loads are in flight together
 #pragma unroll 1
-        for (int q = 0; q < G; ++q) {
-            const int src = q * EPP + lane / G;                   // the lane that walked this group's env
-            const int dd = __shfl(d, src);
-            const int nn = __shfl(n_data, src);
-            const int on = __shfl(act, src);
-            const uint32_t eq = blockIdx.x * 64u + (uint32_t)src;
-            uint32_t flj = 0;
-            if (on && j != dd) {
-                const size_t row = (size_t)eq * RP;
-                const double a0 = st.rxp[row + j];
-                const double pa = PER_ENV ? st.prx_env[((size_t)eq * R + RRM) * RP + j] : s_prx[RRM * R + j];
-                const double pd = (nn == 0) ? 0.0 : (PER_ENV ? st.prx_env[((size_t)eq * R + dd) * RP + j] : s_prx[dd * R + j]);
-                const double a = heard(a0, pa, pd, nn);
-                if (!(a >= 0.0)) flj = GW_FLAG_REFEXC;
-                if (a != a0) st_(st.rxp, (row + j) * 8u, a);
-            }
-            // "the reference would raise" of any listener of the env: OR across the group, one atomic by its first lane
+        for (int q0 = 0; q0 < G; q0 += PQ) {
+            int dd[PQ], nn[PQ], on[PQ];
+            uint32_t eq[PQ];
+            double a0[PQ], pa[PQ], pd[PQ];
 #pragma unroll
-            for (int o = G >> 1; o > 0; o >>= 1) flj |= (uint32_t)__shfl_xor((int)flj, o);
-            if (j == 0 && flj) __hip_atomic_fetch_or(st.sa + (size_t)3 * N + eq, flj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < PQ; ++u) {
+                const int src = (q0 + u) * EPP + lane / G;        // the lane that walked this group's env
+                dd[u] = __shfl(d, src);
+                nn[u] = __shfl(n_data, src);
+                on[u] = __shfl(act, src) && j != dd[u];
+                eq[u] = blockIdx.x * 64u + (uint32_t)src;
+                const uint32_t es = on[u] ? eq[u] : (blockIdx.x * 64u < N ? blockIdx.x * 64u : 0u);   // (a valid row for idle lanes)
+                const size_t row = (size_t)es * RP;
+                a0[u] = st.rxp[row + j];
+                pa[u] = PER_ENV ? st.prx_env[((size_t)es * R + RRM) * RP + j] : s_prx[RRM * R + j];
+                const int dr = on[u] ? dd[u] : 0;
+                pd[u] = PER_ENV ? st.prx_env[((size_t)es * R + dr) * RP + j] : s_prx[dr * R + j];
+            }
+#pragma unroll
+            for (int u = 0; u < PQ; ++u) {
+                uint32_t flj = 0;
+                if (on[u]) {
+                    const double a = heard(a0[u], pa[u], pd[u], nn[u]);
+                    if (!(a >= 0.0)) flj = GW_FLAG_REFEXC;
+                    if (a != a0[u]) st_(st.rxp, ((size_t)eq[u] * RP + j) * 8u, a);
+                }
+                // "the reference would raise" of any listener of the env: OR across the group, one atomic by its first lane
+#pragma unroll
+                for (int o = G >> 1; o > 0; o >>= 1) flj |= (uint32_t)__shfl_xor((int)flj, o);
+                if (j == 0 && flj) __hip_atomic_fetch_or(st.sa + (size_t)3 * N + eq[u], flj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -451,7 +487,9 @@ __global__ void ct_set_position_kernel(GwState st, GwDevConst c, int radio, cons
     const int D = c.D, R = D + 1, RP = gw_rp(R);
     double* pos = st.pos_env + (size_t)e * R * 2;
     double* prx = st.prx_env + (size_t)e * R * RP;
-    const uint64_t talk = st.talk[e];
+    uint64_t talk = 0;                                                    // bit r: radio r has transmitted
+    if (st.talk) talk = st.talk[e];                                       // (explicit-queue mode keeps the mask in its own array)
+    else for (int r = 0; r < R; ++r) talk |= (uint64_t)(st.qb[(size_t)e * st.RB + D + r] & 1u) << r;
     const int a_lo = radio >= 0 ? radio : 0, a_hi = radio >= 0 ? radio + 1 : R;
     bool moved_any = false;
     for (int a = a_lo; a < a_hi; ++a) {

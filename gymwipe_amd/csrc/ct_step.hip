@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
 {
     const int64_t N = st.N;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const GwDevConst& c = *st.cst;
+    // the handle's constants BY VALUE through the constant address space (scalar loads the compiler may hoist and keep;
+    // through the plain reference every use was a fresh global load); run-time indexed members go through the pointer
+    const GwDevConst* cp = st.cst;
+    const GwDevConst c = *(const GW_AS_CONST GwDevConst*)st.cst;
     const int D = DT > 0 ? DT : c.D;
     const int R = D + 1, S = GW_MAX_NSTATES, RRM = D;
 
@@ -159,8 +162,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             }
             GwRunQ rd = load_q(qr_d);
             uint64_t* ring_d = st.runs + (((int64_t)e * D + d) << 7);
-            const uint32_t mult_d = (uint32_t)c.mult[d];
-            const uint32_t inv20_d = c.inv20[d];
+            const uint32_t mult_d = (uint32_t)cp->mult[d];
+            const uint32_t inv20_d = cp->inv20[d];
             int n_data = 0;
             uint32_t n_ticks = 0;                                         // counter ticks inside this step
             const uint8_t s_r_old = DYN ? (uint8_t)0 : st.rxs[(int64_t)RRM * N + e];
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             if (DYN) { rx_r = rx_r0 = gw_rx(st, R, RRM, e); p_x = lp(d, RRM); }
             // receive-mode MAC at the destination (simple_stack.py:443-448): it is idle during d's window (its own
             // window, the only thing that blocks its phyIn handler, ended a slot before the previous step did)
-            const int j_peer = (c.peer_receive && c.dest[d] != d) ? c.dest[d] : -1;
+            const int dest_d = c.peer_receive ? cp->dest[d] : d;
+            const int j_peer = (c.peer_receive && dest_d != d) ? dest_d : -1;
             uint8_t s_p = 0, s_p_old = 0;
             uint32_t n_peer = 0;
             if (j_peer >= 0) {
@@ -209,12 +213,31 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 n_ticks += kk;
             };
 
+            // the same in one jump where the step qualifies (gw_fastmath.h: preconditions once per step, then a dozen
+            // instructions per call), else by the loop
+            double delta = 0.0;
+            const bool span_ok = c.fast_ticks && gw_tick_span_ok(wake, t_end, interval, &delta);
+            auto ticks_upto = [&](double t, bool inclusive) __attribute__((always_inline)) {
+                uint32_t nj = 0;
+                double wj = wake;
+                bool tiej = false, sane = false;
+                gw_tick_jump_lo(wake, t, delta, c.inv_interval_lo, inclusive, &nj, &wj, &tiej, &sane);
+                if (span_ok && sane) {
+                    wake = wj;
+                    if (tiej) fl |= GW_FLAG_TIE;
+                    gw_runq_ticks(rd, nj, ctr0 + n_ticks, bound, base_bytes, ring_d, mult_d, inv20_d, k);
+                    n_ticks += nj;
+                } else {
+                    ticks_to(t, inclusive);
+                }
+            };
+
             if (granted) {
                 const double total = (double)slots * slot;               // simple_stack.py:400
                 const double stopw = t_r + total;                        // :401 (== timeout time :406)
                 double cur = t_r;
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
-                ticks_to(cur, false);
+                ticks_upto(cur, false);
                 for (;;) {
                     if (rd.len == 0u) {                                   // :409-416
                         // (a silent sender, mult 0, never signals packet-added: the MAC waits for the timeout)
@@ -274,36 +297,23 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
                     // ticks are older events than the MAC's resume at t_e: they go first
-                    ticks_to(x.t_e, true);
+                    ticks_upto(x.t_e, true);
                     cur = x.t_e;
                     if (!(cur < stopw)) break;                            // window timeout already processed
                 }
             }
 
-            // ---- A.5: remaining ticks up to the end of the step: in one jump (gw_fastmath.h; exact, validated at
-            //      gw_create) or, where the jump declines, by the loop ----------------------------
-            {
-                uint32_t nj = 0;
-                double wj = wake;
-                bool tiej = false;
-                if (c.fast_ticks && gw_tick_jump(wake, t_end, interval, c.inv_interval, true, &nj, &wj, &tiej)) {
-                    wake = wj;
-                    if (tiej) fl |= GW_FLAG_TIE;
-                    gw_runq_ticks(rd, nj, ctr0 + n_ticks, bound, base_bytes, ring_d, mult_d, inv20_d, k);
-                    n_ticks += nj;
-                } else {
-                    ticks_to(t_end, true);
-                }
-            }
+            // ---- A.5: remaining ticks up to the end of the step ----------------------------
+            ticks_upto(t_end, true);
             st.qrec[(int64_t)d * N + e] = store_q(rd);
 #pragma unroll
             for (int i = 0; i < (DT > 0 ? DT : D); ++i) {
                 if (i == d) continue;
                 // the same n_ticks ticks d's walk just counted (all senders tick together)
-                const uint32_t mult_i = (uint32_t)c.mult[i];
+                const uint32_t mult_i = (uint32_t)(DT > 0 ? c.mult[i] : cp->mult[i]);
                 if (n_ticks != 0u && mult_i != 0u) {
                     GwRunQ ri = load_q(DT > 0 ? qr[DT > 0 ? i : 0] : st.qrec[(int64_t)i * N + e]);
-                    gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, c.inv20[i], k);
+                    gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, DT > 0 ? c.inv20[i] : cp->inv20[i], k);
                     st.qrec[(int64_t)i * N + e] = store_q(ri);
                 }
             }

@@ -1,10 +1,13 @@
 // grid_phy.hip -- N replicas of the reference's PHY grid benchmark (tests/test_benchmark.py:20-91),
 // the workload with concurrent transmissions and a real all-pairs interference sum.
 //
-// One wave per replica, one lane per radio.  Every lane keeps ITS device's pending events
-// (at most one of each kind) in registers; the next event of the replica is the wave-wide minimum over
-// (time, priority, insertion id) -- SimPy's heap order -- found with a shuffle butterfly.  The event's
-// handler then runs with all lanes in parallel wherever the model loops over radios:
+// One lane per radio, one GROUP of GW lanes per replica (GW = the power of two >= n: 4, 8, 16, 32 or 64), 64 / GW replicas
+// per wave: at n = 4 sixteen replicas share a wave and a replica's reductions are two shuffle stages instead of six
+// (round 1 and 2 gave every replica a whole wave: 60 idle lanes at n = 4).  Every lane keeps ITS device's pending events
+// (at most one of each kind) in registers; the next event of a replica is the group-wide minimum over
+// (time, priority, insertion id) -- SimPy's heap order -- found with a width-GW shuffle butterfly.  Each group pops its
+// own event, so the handler switch diverges across groups: one pass of the loop runs every handler some group needs and
+// retires one event PER GROUP.  A handler runs with the group's lanes in parallel wherever the model loops over radios:
 //     NOTIFY  (a transmission starts)  every other radio adds its received power  simple_stack.py:130-144
 //     END     (it completes)           ... and subtracts it again                 :146-157
 //     power change while receiving     count bit errors, re-evaluate the BER      :161-188,:223-231
@@ -78,22 +81,30 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
 
-template <bool MOBILE>
+template <bool MOBILE, int GW>
 __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double seconds)
 {
-    const int lane = threadIdx.x;
+    constexpr int G = 64 / GW;                           // replicas per wave
+    const int wl = threadIdx.x;                          // lane of the wave
+    const int grp = wl / GW;
+    const int lane = wl % GW;                            // this lane's radio within its replica
+    const int gsh = grp * GW;                            // the group's first lane (ballot masks are shifted down by it)
+    const unsigned long long gmask = GW == 64 ? ~0ull : ((1ull << GW) - 1ull);
     const int n = g.n;
-    const int64_t env = blockIdx.x;
-    const bool me = lane < n;                            // this lane is a radio
+    const int64_t env = (int64_t)blockIdx.x * G + grp;
+    const bool have = env < g.N;                         // this group has a replica
+    const bool me = have && lane < n;                    // this lane is a radio
 
-    // ---- static link table -> LDS: prx[from][to] (mW) -------------------------------------------------
-    // static: prx[from][to]; mobile: the power each radio STORED for each active transmission
-    // (simple_stack.py:78,136), plus the current positions
-    extern __shared__ double s_prx[];
+    // ---- link tables -> LDS, one slice per group: static prx[from][to] (mW); mobile: the power each radio STORED for each
+    // active transmission (simple_stack.py:78,136), plus the current positions
+    extern __shared__ double s_all[];
+    double* s_prx = s_all + (size_t)grp * (n * n + 2 * n);
     double* s_px = s_prx + n * n;
     double* s_py = s_px + n;
-    if (MOBILE) { for (int i = lane; i < n * n; i += 64) s_prx[i] = g.txp[env * n * n + i]; }
-    else        { for (int i = lane; i < n * n; i += 64) s_prx[i] = g.prx[i]; }
+    if (have) {
+        if (MOBILE) { for (int i = lane; i < n * n; i += GW) s_prx[i] = g.txp[env * n * n + i]; }
+        else        { for (int i = lane; i < n * n; i += GW) s_prx[i] = g.prx[i]; }
+    }
 
     // ---- state -> registers -----------------------------------------------------------------------------
     GwGridLane L;
@@ -101,10 +112,14 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
     else {
         for (int k = 0; k < EV_COUNT; ++k) { L.ev_t[k] = kInf; L.ev_k[k] = 0xffffffffu; }
         L.rx_power = 0; L.flags = 0; L.px = 0; L.py = 0; L.tx_on = 0;
+        L.started = L.handler_running = L.transmitting = L.receiving = L.waiting_rx = L.rx_running = L.rx_phase = 0;
+        L.queued = 0; L.rx_src = 0; L.rxi_src = 0;
     }
     if (MOBILE && me) { s_px[lane] = L.px; s_py[lane] = L.py; }
     __syncthreads();
-    GwGridEnv E = g.envs[env];                           // wave-uniform: now, eid, counters
+    GwGridEnv E;                                         // group-uniform: now, eid, counters
+    if (have) E = g.envs[env];
+    else { E.now = 0.0; E.eid = 0; E.events = 0; E.n_tx = 0; E.first_run = 0; }
     double now = E.now;
     uint32_t eid = E.eid;
     uint32_t n_events = E.events, n_tx = E.n_tx;
@@ -118,6 +133,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
         E.first_run = 0;
     }
     else k_stop = eid++;
+    bool running = have;                                 // this group's replica has not reached its stop event yet
 
     const double slot = g.slot, interval = g.send_interval, br = g.bit_rate;
     const double hdr_bits = g.hdr_bits, pay_bits = g.pay_bits, hd = g.hdr_dur, pd = g.pay_dur;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
     };
 
     for (;;) {
-        // ---- pop: minimum over (time, key) of every lane's pending events ---------------------------------
+        // ---- pop: minimum over (time, key) of every pending event of the group's lanes --------------------------
         double bt = kInf; uint32_t bk = 0xffffffffu; int bkind = 0;
 #pragma unroll
         for (int k = 0; k < EV_COUNT; ++k) {
@@ -144,24 +160,29 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
             if (better) { bt = L.ev_t[k]; bk = L.ev_k[k]; bkind = k; }
         }
         int bwho = lane;
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ot = __shfl_xor(bt, off, 64);
-            const uint32_t ok = __shfl_xor(bk, off, 64);
-            const int okind = __shfl_xor(bkind, off, 64);
-            const int owho = __shfl_xor(bwho, off, 64);
+#pragma unroll
+        for (int off = GW / 2; off > 0; off >>= 1) {
+            const double ot = __shfl_xor(bt, off, GW);
+            const uint32_t ok = __shfl_xor(bk, off, GW);
+            const int okind = __shfl_xor(bkind, off, GW);
+            const int owho = __shfl_xor(bwho, off, GW);
             if (ot < bt || (ot == bt && ok < bk)) { bt = ot; bk = ok; bkind = okind; bwho = owho; }
         }
         // the stop event: URGENT, created at the start of this run
-        if (!(bt < t_stop_at || (bt == t_stop_at && bk < k_stop))) { now = t_stop_at; break; }
-        now = bt;
-        n_events++;
-        if (n_events - E.events > g.max_events) { if (me) L.flags |= GW_FLAG_CARRY; break; }   // every wave reaches this: no hang
-        const int dev = bwho;                             // wave-uniform
-        const bool mine = me && lane == dev;
+        if (running && !(bt < t_stop_at || (bt == t_stop_at && bk < k_stop))) { now = t_stop_at; running = false; }
+        if (running) {
+            now = bt;
+            n_events++;
+            if (n_events - E.events > g.max_events) { if (me) L.flags |= GW_FLAG_CARRY; running = false; }   // every group reaches this: no hang
+        }
+        if (!__any(running)) break;                       // (wave-uniform: every lane leaves together)
+        const int dev = bwho;                             // group-uniform
+        const bool mine = me && lane == dev && running;
         if (mine) {
 #pragma unroll
             for (int k = 0; k < EV_COUNT; ++k) if (k == bkind) { L.ev_t[k] = kInf; L.ev_k[k] = 0xffffffffu; }
         }
+        if (!running) bkind = EV_COUNT;                   // a finished group runs no handler while the others go on
 
         switch (bkind) {
         case EV_TICK: {
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
                 push(EV_TICK, now + interval, kNormal | (eid + inc));
                 inc += 1;
             }
-            eid += __shfl(inc, dev, 64);
+            eid += __shfl(inc, dev, GW);
             break;
         }
         case EV_HINIT: {
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
                 if (L.receiving) L.waiting_rx = 1;        // yield nReceivingFinished.event: nothing is scheduled
                 else { L.transmitting = 1; push(EV_SLOT, now + (slot - fmod(now, slot)), kNormal | eid); inc = 1; }
             }
-            eid += __shfl(inc, dev, 64);
+            eid += __shfl(inc, dev, GW);
             break;
         }
         case EV_RXFIN: {
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
             break;
         }
         case EV_NOTIFY: {
-            const double stop_dev = __shfl(L.tx_stop, dev, 64);
+            const double stop_dev = __shfl(L.tx_stop, dev, GW);
             if (mine) L.tx_on = 1;
             if (me && lane != dev) {                      // _onNewTransmission at every other radio
                 double p;
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
             }
             // receive-process admission, blocking and not queued, in radio order (the sender too)
             const bool start = me && !L.rx_running;
-            const unsigned long long m = __ballot(start);
+            const unsigned long long m = (__ballot(start) >> gsh) & gmask;   // this group's lanes
             if (start) {
                 L.rx_running = 1;
                 L.rxi_src = dev;
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
                     inc = 1;
                 }
             }
-            eid += __shfl(inc, dev, 64);
+            eid += __shfl(inc, dev, GW);
             break;
         }
         case EV_HDR: {                                    // receivers of `dev` in the header phase, radio order
@@ -274,8 +295,9 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
             // a failing receiver: [RXFIN if its handler waits] then RXPROC, lane by lane
             const int pushes = fail ? (L.waiting_rx ? 2 : 1) : 0;
             int before = pushes;                          // exclusive prefix sum over lanes
-            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(before, off, 64); if (lane >= off) before += v; }
-            const int total = __shfl(before, 63, 64);
+#pragma unroll
+            for (int off = 1; off < GW; off <<= 1) { const int v = __shfl_up(before, off, GW); if (lane >= off) before += v; }
+            const int total = __shfl(before, GW - 1, GW);
             before -= pushes;
             if (fail) {
                 L.receiving = 0; L.err_sum = 0.0; L.ber = 0.0; L.t_seg = now;
@@ -307,8 +329,9 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
             }
             const int pushes = rx ? (L.waiting_rx ? 2 : 1) : 0;
             int before = pushes;
-            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(before, off, 64); if (lane >= off) before += v; }
-            const int total = __shfl(before, 63, 64);
+#pragma unroll
+            for (int off = 1; off < GW; off <<= 1) { const int v = __shfl_up(before, off, GW); if (lane >= off) before += v; }
+            const int total = __shfl(before, GW - 1, GW);
             before -= pushes;
             if (rx) {
                 L.receiving = 0; L.err_sum = 0.0; L.ber = 0.0; L.t_seg = now;
@@ -335,8 +358,10 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
                     push(EV_MOVE, now + g.move_interval, kNormal | eid);
                 }
                 eid += 1;
-                __syncthreads();
-                const unsigned long long on_air = __ballot(me && L.tx_on);
+                // (one wave per workgroup, LDS operations of a wave complete in order: the positions just written are what the
+                //  group's other lanes read below; a workgroup barrier has no place inside a handler only some groups run)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const unsigned long long on_air = (__ballot(me && L.tx_on) >> gsh) & gmask;
                 // (A) the mover's own transmission, heard by everyone else: _onAttenuationChange (simple_stack.py:119-128)
                 if ((on_air >> dev) & 1ull) {
                     if (me && lane != dev) {
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
                         }
                     }
                 }
-                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             break;
         }
@@ -376,16 +401,17 @@ __global__ __launch_bounds__(64) void grid_run_kernel(GwGridDev g, double second
                 if (L.queued) { L.queued--; push(EV_HINIT, now, eid); inc = 1; }        // URGENT
                 else L.handler_running = 0;
             }
-            eid += __shfl(inc, dev, 64);
+            eid += __shfl(inc, dev, GW);
             break;
         }
         }
     }
 
     // ---- registers -> state -----------------------------------------------------------------------------
-    if (MOBILE) { __syncthreads(); for (int i = lane; i < n * n; i += 64) g.txp[env * n * n + i] = s_prx[i]; }
+    __syncthreads();
+    if (MOBILE && have) { for (int i = lane; i < n * n; i += GW) g.txp[env * n * n + i] = s_prx[i]; }
     if (me) g.lanes[env * n + lane] = L;
-    if (lane == 0) {
+    if (have && lane == 0) {
         E.now = now; E.eid = eid; E.events = n_events; E.n_tx = n_tx;
         g.envs[env] = E;
     }
@@ -486,9 +512,21 @@ __global__ void grid_init_kernel(GwGridDev g, const double* __restrict__ delays,
 
 int gw_grid_launch_run(const GwGridDev& g, double seconds, void* stream)
 {
-    const size_t lds = ((size_t)g.n * g.n + 2 * (size_t)g.n) * sizeof(double);
-    if (g.mobile) hipLaunchKernelGGL(grid_run_kernel<true>, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
-    else          hipLaunchKernelGGL(grid_run_kernel<false>, dim3((unsigned)g.N), dim3(64), lds, (hipStream_t)stream, g, seconds);
+    // lanes per replica: the power of two that holds its radios; 64 / GW replicas share a wave
+    int gw = g.n <= 4 ? 4 : (g.n <= 8 ? 8 : (g.n <= 16 ? 16 : (g.n <= 32 ? 32 : 64)));
+    // ... unless that leaves SIMDs without a wave (1 024 of them): a small batch spreads out first (4 096 replicas of 4 radios:
+    // groups of 16 lanes, four replicas per wave, 1 024 waves -- sixteen per wave would be 256 waves on a quarter of the chip)
+    while (gw < 64 && (g.N * gw + 63) / 64 < 1024) gw *= 2;
+    const int per_wave = 64 / gw;
+    const size_t lds = (size_t)per_wave * ((size_t)g.n * g.n + 2 * (size_t)g.n) * sizeof(double);
+    const unsigned grid = (unsigned)((g.N + per_wave - 1) / per_wave);
+    hipStream_t s = (hipStream_t)stream;
+#define GW_GRID(M_, W_) hipLaunchKernelGGL((grid_run_kernel<M_, W_>), dim3(grid), dim3(64), lds, s, g, seconds)
+    if (g.mobile) { switch (gw) { case 4: GW_GRID(true, 4); break; case 8: GW_GRID(true, 8); break; case 16: GW_GRID(true, 16); break;
+                                  case 32: GW_GRID(true, 32); break; default: GW_GRID(true, 64); break; } }
+    else          { switch (gw) { case 4: GW_GRID(false, 4); break; case 8: GW_GRID(false, 8); break; case 16: GW_GRID(false, 16); break;
+                                  case 32: GW_GRID(false, 32); break; default: GW_GRID(false, 64); break; } }
+#undef GW_GRID
     return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
 }
 

@@ -74,23 +74,53 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
     Tally k = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
 
-    // per-sender queue records, issued before anything depends on them
+    // {multiplicity, ceil(2^20 / multiplicity), dest} per sender: looked up by the lane's action -- from LDS, not by a global
+    // round trip that can only start once the action has arrived
+    __shared__ int s_mult[DM], s_inv20[DM], s_dest[DM];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) { s_mult[i] = cp->mult[i]; s_inv20[i] = (int)cp->inv20[i]; s_dest[i] = cp->dest[i]; }
+
+    // the env's packed records and per-sender queue records, issued before anything depends on them: {now, wake},
+    // {counter, rvmask, last_abs | done << 31, flags}, the noise-state bytes of all radios
     constexpr int DR = DT > 0 ? DT : 1;
+    constexpr int NXW = DT > 0 ? (DT + 1 + 15) / 16 : 1;          // 16-byte words of the noise-state record
+    const int64_t el = e < N ? e : 0;
     GwRec qr[DR];
-    if (DT > 0 && e < N) {
+    if (DT > 0) {
 #pragma unroll
-        for (int i = 0; i < DR; ++i) qr[i] = st.qrec[(int64_t)i * N + e];
+        for (int i = 0; i < DR; ++i) qr[i] = st.qrec[(int64_t)i * N + el];
     }
+    const double2 xw0 = reinterpret_cast<const double2*>(st.xw)[el];
+    const uint4 xc0 = reinterpret_cast<const uint4*>(st.xc)[el];
+    uint4 xsw[NXW];
+#pragma unroll
+    for (int w = 0; w < NXW; ++w) xsw[w] = DT > 0 ? reinterpret_cast<const uint4*>(st.xs + (size_t)el * st.XB)[w] : make_uint4(0u, 0u, 0u, 0u);
+    const int d = device[el];
+    const int du = duration[el];
     __syncthreads();
+    // noise state of radio j (run-time j): from the record's registers (DT > 0) or from memory
+    auto xs_get = [&](int j) -> uint8_t {
+        if (DT > 0) {
+            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+            for (int w = 0; w < NXW; ++w) {
+                // (opaque register values first: selecting struct fields by a run-time index becomes a stack copy)
+                uint32_t a0 = xsw[w].x, a1 = xsw[w].y, a2 = xsw[w].z, a3 = xsw[w].w;
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+                const bool h = (j >> 4) == w;
+                w0 = h ? a0 : w0; w1 = h ? a1 : w1; w2 = h ? a2 : w2; w3 = h ? a3 : w3;
+            }
+            const uint32_t lo = (j & 4) ? w1 : w0, hi = (j & 4) ? w3 : w2;
+            const uint32_t v = (j & 8) ? hi : lo;
+            return (uint8_t)((v >> ((j & 3) * 8)) & 0xffu);
+        }
+        return st.xs[(size_t)e * st.XB + j];
+    };
 
     if (e < N) {
-        const int d = device[e];
-        const int du = duration[e];
-        uint32_t fl = st.flags[e];
-        const uint32_t fl_old = fl;
-        uint32_t rvm = st.rvmask[e];
-        int32_t last_abs = st.last_abs[e];
-        uint8_t dn = st.done[e];
+        uint32_t fl = xc0.w;
+        uint32_t rvm = xc0.y;
+        int32_t last_abs = (int32_t)(xc0.z & 0x7fffffffu);
+        uint8_t dn = (uint8_t)(xc0.z >> 31);
         const int pv = c.payload_value;
 
         if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
@@ -101,6 +131,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             obs[e] = latest + c.counter_bound;
             reward[e] = 0.0f;
             done[e] = dn;
+            if (fl != xc0.w) st.xc[(size_t)e * 4 + 3] = fl;
         } else {
             k_steps = 1;
             const StepMath m(c);
@@ -111,9 +142,9 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const uint32_t base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
             const int mh = c.mac_hdr;
 
-            const double t_a = st.now[e];
-            double wake = st.wake[e];
-            const uint32_t ctr0 = st.counter[e];
+            const double t_a = xw0.x;
+            double wake = xw0.y;
+            const uint32_t ctr0 = xc0.x;
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
             // ---- A.1 / A.2: announcement ---------------------------------------------
@@ -137,7 +168,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 granted = receive(m, ber_bpsk_dev(p_a, noise, c.ten_log_br), an, br, hdr_bits, (double)(La * 8) * c.coded_factor, fl);
                 gw_rx(st, R, d, e) = up + (-p_a);
             } else {
-                s_d_old = st.rxs[(int64_t)d * N + e];
+                s_d_old = xs_get(d);
                 s_d = s_h1[d * S + s_d_old];
                 granted = decode(m, s_cls[d * S + s_d], cls_valid, s_ber[d * S + s_d], an, br, hdr_bits,
                                  (double)(La * 8) * c.coded_factor, fl);
@@ -162,22 +193,34 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             }
             GwRunQ rd = load_q(qr_d);
             uint64_t* ring_d = st.runs + (((int64_t)e * D + d) << 7);
-            const uint32_t mult_d = (uint32_t)cp->mult[d];
-            const uint32_t inv20_d = cp->inv20[d];
+            const uint32_t mult_d = (uint32_t)s_mult[d];
+            const uint32_t inv20_d = (uint32_t)s_inv20[d];
             int n_data = 0;
             uint32_t n_ticks = 0;                                         // counter ticks inside this step
-            const uint8_t s_r_old = DYN ? (uint8_t)0 : st.rxs[(int64_t)RRM * N + e];
+            const uint8_t s_r_old = DYN ? (uint8_t)0 : xs_get(RRM);
             uint8_t s_r = s_r_old;
             const uint8_t s_r1 = DYN ? (uint8_t)0 : s_rr[d * S + s_r_old];        // the RRM after one packet of d
             const double ber_x1 = DYN ? 0.0 : s_ber[(D + d) * S + s_r1];
             const uint32_t cls_x1 = DYN ? 0u : s_cls[(D + d) * S + s_r1];
+            // every other radio's noise state after the announcement (n1) and after the announcement AND >= 1 data packet of d
+            // (n2): looked up NOW, consumed after the window -- a load issued behind the step's first stores would wait for
+            // those stores to complete (vmcnt counts loads and stores in one order), a microsecond apiece
+            uint8_t n1[DR], n2[DR];
+            if (DT > 0 && !DYN) {
+#pragma unroll
+                for (int j = 0; j < DR; ++j) {
+                    const uint8_t s0 = xs_get(j);
+                    n1[j] = s_h1[j * S + s0];
+                    n2[j] = g_h2[(j * D + d) * S + s0];
+                }
+            }
             // live PHY: the RRM's (and a receive-mode peer's) received power, and the BER cached per noise value
             double rx_r = 0.0, rx_r0 = 0.0, p_x = 0.0, ber_xd = 0.0, nz_r_prev = -1.0;
             double rx_p = 0.0, rx_p0 = 0.0, p_p = 0.0, ber_pd = 0.0, nz_p_prev = -1.0;
             if (DYN) { rx_r = rx_r0 = gw_rx(st, R, RRM, e); p_x = lp(d, RRM); }
             // receive-mode MAC at the destination (simple_stack.py:443-448): it is idle during d's window (its own
             // window, the only thing that blocks its phyIn handler, ended a slot before the previous step did)
-            const int dest_d = c.peer_receive ? cp->dest[d] : d;
+            const int dest_d = c.peer_receive ? s_dest[d] : d;
             const int j_peer = (c.peer_receive && dest_d != d) ? dest_d : -1;
             uint8_t s_p = 0, s_p_old = 0;
             uint32_t n_peer = 0;
@@ -188,7 +231,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     rx_p = (rx_p0 + pa) + (-pa);                              // it heard the announcement too
                     p_p = lp(d, j_peer);
                 } else {
-                    s_p_old = st.rxs[(int64_t)j_peer * N + e];
+                    s_p_old = xs_get(j_peer);
                     s_p = st.trans[((int64_t)j_peer * R + RRM) * S + s_p_old];    // it heard the announcement too
                 }
             }
@@ -305,17 +348,35 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
 
             // ---- A.5: remaining ticks up to the end of the step ----------------------------
             ticks_upto(t_end, true);
-            st.qrec[(int64_t)d * N + e] = store_q(rd);
+            // the same n_ticks ticks d's walk just counted reach every other sender's queue (all senders tick together); the
+            // records are STORED at the very end of the step, behind every load (see above)
+            const GwRec rec_d = store_q(rd);
+            GwRec qout[DR];
+            if (DT > 0) {
 #pragma unroll
-            for (int i = 0; i < (DT > 0 ? DT : D); ++i) {
-                if (i == d) continue;
-                // the same n_ticks ticks d's walk just counted (all senders tick together)
-                const uint32_t mult_i = (uint32_t)(DT > 0 ? c.mult[i] : cp->mult[i]);
-                if (n_ticks != 0u && mult_i != 0u) {
-                    GwRunQ ri = load_q(DT > 0 ? qr[DT > 0 ? i : 0] : st.qrec[(int64_t)i * N + e]);
-                    gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, DT > 0 ? c.inv20[i] : cp->inv20[i], k);
-                    st.qrec[(int64_t)i * N + e] = store_q(ri);
+                for (int i = 0; i < DR; ++i) {
+                    GwRec ro = qr[i];
+                    const uint32_t mult_i = (uint32_t)c.mult[i];
+                    if (i != d && n_ticks != 0u && mult_i != 0u) {
+                        GwRunQ ri = load_q(qr[i]);
+                        gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, c.inv20[i], k);
+                        ro = store_q(ri);
+                    }
+                    const bool hit = i == d;
+                    qout[i].x = hit ? rec_d.x : ro.x; qout[i].y = hit ? rec_d.y : ro.y;
+                    qout[i].z = hit ? rec_d.z : ro.z; qout[i].w = hit ? rec_d.w : ro.w;
                 }
+            } else {
+                for (int i = 0; i < D; ++i) {
+                    if (i == d) continue;
+                    const uint32_t mult_i = (uint32_t)s_mult[i];
+                    if (n_ticks != 0u && mult_i != 0u) {
+                        GwRunQ ri = load_q(st.qrec[(int64_t)i * N + e]);
+                        gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, (uint32_t)s_inv20[i], k);
+                        st.qrec[(int64_t)i * N + e] = store_q(ri);
+                    }
+                }
+                st.qrec[(int64_t)d * N + e] = rec_d;
             }
             uint32_t ctr_new = ctr0 + n_ticks;                            // `if counter < bound: counter += 1` per tick
             ctr_new = (ctr0 >= bound) ? ctr0 : (ctr_new < bound ? ctr_new : bound);
@@ -345,23 +406,52 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     if (a != a0) gw_rx(st, R, j, e) = a;
                 }
             } else {
-                if (s_d != s_d_old) st.rxs[(int64_t)d * N + e] = s_d;         // d hears only the announcement
-                if (s_r != s_r_old) st.rxs[(int64_t)RRM * N + e] = s_r;
-                if (j_peer >= 0) {
-                    if (s_p != s_p_old) st.rxs[(int64_t)j_peer * N + e] = s_p;
-                    if (n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
-                }
-                for (int j = 0; j < D; ++j) {
-                    if (j == d || j == j_peer) continue;
-                    const uint8_t s0 = st.rxs[(int64_t)j * N + e];
-                    uint8_t s;
+                if (j_peer >= 0 && n_peer) st.peer_rx[(int64_t)j_peer * N + e] += n_peer;
+                // every other radio heard the announcement and, if any, d's data; d heard only the announcement
+                auto after = [&](int j, uint8_t s0) -> uint8_t {
+                    if (j == d) return s_d;
+                    if (j == j_peer) return s_p;
                     if (idem) {
-                        s = n_data ? g_h2[(j * D + d) * S + s0] : s_h1[j * S + s0];
-                    } else {
-                        s = st.trans[((int64_t)j * R + RRM) * S + s0];
-                        for (int n = 0; n < n_data; ++n) s = st.trans[((int64_t)j * R + d) * S + s];
+                        // (two typed loads and a select of the VALUES: a select between the LDS pointer and the global one is
+                        //  a generic pointer, whose flat load waits for every outstanding store of the wave)
+                        const uint8_t a = DT > 0 ? n2[DT > 0 ? j : 0] : g_h2[(j * D + d) * S + s0];
+                        const uint8_t b = DT > 0 ? n1[DT > 0 ? j : 0] : s_h1[j * S + s0];
+                        return n_data ? a : b;
                     }
-                    if (s != s0) st.rxs[(int64_t)j * N + e] = s;
+                    uint8_t sj = st.trans[((int64_t)j * R + RRM) * S + s0];
+                    for (int n = 0; n < n_data; ++n) sj = st.trans[((int64_t)j * R + d) * S + sj];
+                    return sj;
+                };
+                if (DT > 0) {
+                    uint32_t nbx[16 * NXW];
+#pragma unroll
+                    for (int b = 0; b < 16 * NXW; ++b) {
+                        const uint4& w = xsw[b >> 4];
+                        const uint32_t word = ((b >> 2) & 3) == 0 ? w.x : (((b >> 2) & 3) == 1 ? w.y : (((b >> 2) & 3) == 2 ? w.z : w.w));
+                        nbx[b] = (word >> ((b & 3) * 8)) & 0xffu;
+                    }
+#pragma unroll
+                    for (int j = 0; j < DT; ++j) nbx[j] = after(j, (uint8_t)nbx[j]);
+                    nbx[DT] = s_r;
+#pragma unroll
+                    for (int w = 0; w < NXW; ++w) {
+                        const int b = 16 * w;
+                        uint4 o;
+                        o.x = nbx[b + 0] | (nbx[b + 1] << 8) | (nbx[b + 2] << 16) | (nbx[b + 3] << 24);
+                        o.y = nbx[b + 4] | (nbx[b + 5] << 8) | (nbx[b + 6] << 16) | (nbx[b + 7] << 24);
+                        o.z = nbx[b + 8] | (nbx[b + 9] << 8) | (nbx[b + 10] << 16) | (nbx[b + 11] << 24);
+                        o.w = nbx[b + 12] | (nbx[b + 13] << 8) | (nbx[b + 14] << 16) | (nbx[b + 15] << 24);
+                        if (o.x != xsw[w].x || o.y != xsw[w].y || o.z != xsw[w].z || o.w != xsw[w].w)
+                            reinterpret_cast<uint4*>(st.xs + (size_t)e * st.XB)[w] = o;
+                    }
+                } else {
+                    uint8_t* xr = st.xs + (size_t)e * st.XB;
+                    for (int j = 0; j < D; ++j) {
+                        const uint8_t s0 = xr[j];
+                        const uint8_t s1 = after(j, s0);
+                        if (s1 != s0) xr[j] = s1;
+                    }
+                    if (s_r != s_r_old) xr[RRM] = s_r;
                 }
             }
 
@@ -375,12 +465,12 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             reward[e] = (float)r;
             done[e] = dn;
 
-            st.now[e] = t_end;
-            st.wake[e] = wake;
-            st.counter[e] = ctr_new;
-            st.rvmask[e] = rvm;
-            st.last_abs[e] = last_abs;
-            st.done[e] = dn;
+            if (DT > 0) {
+#pragma unroll
+                for (int i = 0; i < DR; ++i) st.qrec[(int64_t)i * N + e] = qout[i];
+            }
+            reinterpret_cast<double2*>(st.xw)[e] = make_double2(t_end, wake);
+            reinterpret_cast<uint4*>(st.xc)[e] = make_uint4(ctr_new, rvm, (uint32_t)last_abs | ((uint32_t)dn << 31), fl);
             if (PER_ENV_STATS) {
                 st.pe_stats[0 * N + e] += k.tx;
                 st.pe_stats[1 * N + e] += k.deliv;
@@ -389,7 +479,6 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 st.pe_stats[4 * N + e] += k.drop;
             }
         }
-        if (fl != fl_old) st.flags[e] = fl;
         fl_new = fl;
     }
 
@@ -403,15 +492,11 @@ __global__ void ct_init_kernel(GwState st)
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
     const int D = st.cst->D, R = st.cst->R;
-    st.now[e] = st.cst->start_time;
-    st.wake[e] = st.cst->no_traffic ? (double)INFINITY : st.cst->start_time;
-    st.counter[e] = 1u;
-    st.rvmask[e] = 0u;
-    st.last_abs[e] = 0;
-    st.done[e] = 0;
-    st.flags[e] = 0u;
+    reinterpret_cast<double2*>(st.xw)[e] = make_double2(st.cst->start_time, st.cst->no_traffic ? (double)INFINITY : st.cst->start_time);
+    reinterpret_cast<uint4*>(st.xc)[e] = make_uint4(1u, 0u, 0u, 0u);      // counter 1 (counter_traffic.py:48), nothing received, no flags
     if (st.qrec) for (int i = 0; i < D; ++i) st.qrec[(int64_t)i * N + e] = GwRec{0u, 0u, 0u, 0u};
-    for (int r = 0; r < R; ++r) st.rxs[(int64_t)r * N + e] = 0;
+    (void)R;
+    for (int b = 0; b < st.XB; ++b) st.xs[(size_t)e * st.XB + b] = 0;
     if (st.pe_stats) for (int s = 0; s < 5; ++s) st.pe_stats[(int64_t)s * N + e] = 0ull;
     if (st.peer_rx) for (int i = 0; i < D; ++i) st.peer_rx[(int64_t)i * N + e] = 0u;
 }
@@ -443,14 +528,13 @@ __global__ void ct_reset_kernel(GwState st, const uint8_t* __restrict__ mask, in
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= st.N) return;
+    uint4 xc = reinterpret_cast<const uint4*>(st.xc)[e];
     if (!mask || mask[e]) {
-        st.counter[e] = 0u;
-        st.rvmask[e] = 0u;
-        st.last_abs[e] = 0;
-        st.done[e] = 0;
+        xc.x = 0u; xc.y = 0u; xc.z = 0u;                   // counter, receivedValues, lastAbs / done; the sticky flags stay
+        reinterpret_cast<uint4*>(st.xc)[e] = xc;
     }
     if (obs) {
-        const uint32_t rvm = st.rvmask[e];
+        const uint32_t rvm = xc.y;
         obs[e] = st.cst->payload_value * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u)) + st.cst->counter_bound;
     }
 }
@@ -462,7 +546,7 @@ __global__ void ct_received_kernel(GwState st, int32_t* __restrict__ out)
     if (idx >= st.N * D) return;
     const int64_t e = idx / D;
     const int i = (int)(idx - e * D);
-    out[idx] = ((st.rvmask[e] >> i) & 1u) ? st.cst->payload_value : 0;
+    out[idx] = ((st.xc[(size_t)e * 4 + 1] >> i) & 1u) ? st.cst->payload_value : 0;
 }
 
 inline int check_launch()

@@ -776,7 +776,7 @@ __global__ void ct_clear_flags_kernel(GwState st)
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < st.N) {
         if (st.sa) st.sa[(size_t)3 * st.N + e] = 0u;
-        if (st.flags) st.flags[e] = 0u;
+        if (st.xc) st.xc[(size_t)e * 4 + 3] = 0u;
     }
     if (st.totals && e < st.n_slots) st.totals[(size_t)e * GW_T_COUNT + GW_T_FLAGS] = 0ull;
 }

@@ -425,10 +425,9 @@ int gw_create(const gw_config* cfg, gw_env** out)
     env->dyn = (per_env_geo || env->tab.overflow) ? 1 : 0;
     uint8_t* d_cls = nullptr; double* d_ber2 = nullptr; uint8_t* d_cls2 = nullptr; uint8_t* d_blob = nullptr;
     if (explicit_q) {
-        TRY_ALLOC(st.now, N);      TRY_ALLOC(st.wake, N);       TRY_ALLOC(st.counter, N);
+        st.XB = 16 * ((R + 15) / 16);
+        TRY_ALLOC(st.xw, N * 2);    TRY_ALLOC(st.xc, N * 4);    TRY_ALLOC(st.xs, N * st.XB);
         TRY_ALLOC(st.qrec, N * D);  TRY_ALLOC(st.runs, N * D * GW_RING_PHYS);
-        TRY_ALLOC(st.rvmask, N);   TRY_ALLOC(st.last_abs, N);   TRY_ALLOC(st.done, N);
-        TRY_ALLOC(st.rxs, N * R);
     } else {
         st.RB = 16 * ((2 * D + 1 + 15) / 16);
         TRY_ALLOC(st.tw, N * 2);   TRY_ALLOC(st.tk, N * 4);
@@ -457,7 +456,6 @@ int gw_create(const gw_config* cfg, gw_env** out)
         if (per_env_geo && explicit_q) TRY_ALLOC(st.talk, N);   // (default queue mode: the mask lives in spare bytes of the qb record)
         st.prx_tab = d_prx; st.pos_tab = d_pos; st.extra_tab = d_extra;
     }
-    if (explicit_q) TRY_ALLOC(st.flags, N);
     if (explicit_q && (cfg->flags & GW_CFG_PEER_RECEIVE)) TRY_ALLOC(st.peer_rx, N * D);
     if (explicit_q && (cfg->flags & GW_CFG_PER_ENV_STATS)) TRY_ALLOC(st.pe_stats, N * 5);
     st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
@@ -780,7 +778,7 @@ int gw_now_ptr(gw_env* env, const void** now_dev, int64_t* stride_bytes)
 {
     if (!env || !now_dev || !stride_bytes) return fail(GW_EINVAL, "env/now/stride is NULL");
     if (env->st.tw) { *now_dev = env->st.tw; *stride_bytes = 16; }          // {now, next tick} records
-    else { *now_dev = env->st.now; *stride_bytes = 8; }
+    else { *now_dev = env->st.xw; *stride_bytes = 16; }                    // explicit-queue mode: the same record shape
     return GW_OK;
 }
 
@@ -1094,37 +1092,31 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
         return fail(GW_EFIELD, "unknown field %s", field);
     }
 
-    if (!strcmp(field, "now")) { NEED(N, double); HIP_TRY(hipMemcpy(dst, st.now, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
-    if (!strcmp(field, "last_abs")) { NEED(N, int32_t); HIP_TRY(hipMemcpy(dst, st.last_abs, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
-    if (!strcmp(field, "flags")) { NEED(N, uint32_t); HIP_TRY(hipMemcpy(dst, st.flags, bytes, hipMemcpyDeviceToHost)); return GW_OK; }
-    if (!strcmp(field, "wake")) {
-        NEED(N * D, double);
-        std::vector<double> w(N);
-        HIP_TRY(hipMemcpy(w.data(), st.wake, N * sizeof(double), hipMemcpyDeviceToHost));
+    // ---- explicit-queue mode: packed records xw {now, wake}, xc {counter, rvmask, last_abs | done << 31, flags} ----
+    if (!strcmp(field, "now") || !strcmp(field, "wake")) {
+        std::vector<double> w((size_t)N * 2);
+        HIP_TRY(hipMemcpy(w.data(), st.xw, w.size() * sizeof(double), hipMemcpyDeviceToHost));
         double* o = (double*)dst;
-        for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = w[e];
+        if (field[0] == 'n') { NEED(N, double); for (int64_t e = 0; e < N; ++e) o[e] = w[e * 2]; }
+        else { NEED(N * D, double); for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = w[e * 2 + 1]; }
         return GW_OK;
     }
-    if (!strcmp(field, "counter") && st.counter) {
-        NEED(N * D, uint32_t);
-        std::vector<uint32_t> c(N);
-        HIP_TRY(hipMemcpy(c.data(), st.counter, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        uint32_t* o = (uint32_t*)dst;
-        for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = c[e];
-        return GW_OK;
-    }
-    if (!strcmp(field, "received") || !strcmp(field, "latest_diff")) {
-        std::vector<uint32_t> m(N);
-        HIP_TRY(hipMemcpy(m.data(), st.rvmask, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (!strcmp(field, "last_abs") || !strcmp(field, "flags") || !strcmp(field, "counter") || !strcmp(field, "received") ||
+        !strcmp(field, "latest_diff")) {
+        std::vector<uint32_t> c((size_t)N * 4);
+        HIP_TRY(hipMemcpy(c.data(), st.xc, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const int pv = env->cfg.payload_value;
-        if (field[0] == 'r') {
-            NEED(N * D, int32_t);
-            int32_t* o = (int32_t*)dst;
-            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ((m[e] >> i) & 1u) ? pv : 0;
+        if (!strcmp(field, "last_abs")) { NEED(N, int32_t); int32_t* o = (int32_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = (int32_t)(c[e * 4 + 2] & 0x7fffffffu); }
+        else if (!strcmp(field, "flags")) { NEED(N, uint32_t); uint32_t* o = (uint32_t*)dst; for (int64_t e = 0; e < N; ++e) o[e] = c[e * 4 + 3]; }
+        else if (!strcmp(field, "counter")) {
+            NEED(N * D, uint32_t); uint32_t* o = (uint32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = c[e * 4];
+        } else if (field[0] == 'r') {
+            NEED(N * D, int32_t); int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) for (int i = 0; i < D; ++i) o[e * D + i] = ((c[e * 4 + 1] >> i) & 1u) ? pv : 0;
         } else {
-            NEED(N, int32_t);
-            int32_t* o = (int32_t*)dst;
-            for (int64_t e = 0; e < N; ++e) o[e] = pv * ((int)(m[e] & 1u) - (int)((m[e] >> 1) & 1u));
+            NEED(N, int32_t); int32_t* o = (int32_t*)dst;
+            for (int64_t e = 0; e < N; ++e) o[e] = pv * ((int)(c[e * 4 + 1] & 1u) - (int)((c[e * 4 + 1] >> 1) & 1u));
         }
         return GW_OK;
     }
@@ -1176,10 +1168,10 @@ int gw_get_state(gw_env* env, const char* field, void* dst, size_t bytes)
     }
     if (!strcmp(field, "rx_power")) {
         NEED(N * R, double);
-        std::vector<uint8_t> s((size_t)N * R);
-        HIP_TRY(hipMemcpy(s.data(), st.rxs, s.size(), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> s((size_t)N * st.XB);
+        HIP_TRY(hipMemcpy(s.data(), st.xs, s.size(), hipMemcpyDeviceToHost));
         double* o = (double*)dst;
-        for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = env->tab.state_val[r][s[(size_t)r * N + e]];
+        for (int64_t e = 0; e < N; ++e) for (int r = 0; r < R; ++r) o[e * R + r] = env->tab.state_val[r][s[(size_t)e * st.XB + r]];
         return GW_OK;
     }
     static const char* pe[5] = {"n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped"};

@@ -51,6 +51,11 @@ struct GwState {
     double*   now;        // [N]        simulated time (SimMan.now)
     double*   wake;       // [N]        next counter tick (all senders tick in lock-step)
     uint32_t* counter;    // [N]        sender.counter (identical for all senders of an env)
+    // explicit-queue mode (GW_CFG_EXPLICIT_QUEUE), packed so that an env's scalars are three 16-byte loads and stores:
+    double*   xw;         // [N][2]     {now, next counter tick}
+    uint32_t* xc;         // [N][4]     {counter, rvmask, last_abs | done << 31, sticky GW_FLAG_* bits}
+    uint8_t*  xs;         // [N][XB]    rx-power state index per radio 0..D (stands for phy._receivedPower), padded to 16 bytes
+    int32_t   XB;         //            bytes per xs record: 16 * ceil((D + 1) / 16)
     // MAC queue (SimpleMac._packetQueue), one of two encodings:
     //  explicit (GW_CFG_EXPLICIT_QUEUE): run-length deques, gw_runq.h
     GwRec*    qrec;       // [D][N]     16-byte record: head run, tail run, bookkeeping

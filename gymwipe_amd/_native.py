@@ -28,7 +28,7 @@ CFG_PER_ENV_GEOMETRY = 32
 EXPORTS = (
     "gw_abi_version", "gw_last_error", "gw_device_count", "gw_config_default", "gw_create",
     "gw_destroy", "gw_reset", "gw_step", "gw_step_fb", "gw_rollout", "gw_set_position", "gw_set_positions", "gw_received", "gw_delivered", "gw_enqueue", "gw_pack_feedback", "gw_unpack_feedback", "gw_get_state",
-    "gw_stats_read", "gw_clear_flags", "gw_state_bytes", "gw_link_info", "gw_noise_states", "gw_selftest_queue", "gw_selftest_runq",
+    "gw_stats_read", "gw_clear_flags", "gw_state_bytes", "gw_snapshot_bytes", "gw_get_snapshot", "gw_set_state", "gw_link_info", "gw_noise_states", "gw_selftest_queue", "gw_selftest_runq",
     "gw_selftest_fastmath",
     "gw_plant_config_default", "gw_plant_create", "gw_plant_destroy", "gw_plant_update", "gw_plant_set_input",
     "gw_plant_state_ptr", "gw_plant_get_state", "gw_plant_feedback", "gw_plant_update_feedback", "gw_now_ptr", "gw_pendulum_step",
@@ -195,6 +195,9 @@ def lib():
     L.gw_get_state.argtypes, L.gw_get_state.restype = [vp, C.c_char_p, vp, C.c_size_t], C.c_int
     L.gw_stats_read.argtypes, L.gw_stats_read.restype = [vp, C.POINTER(Stats)], C.c_int
     L.gw_state_bytes.argtypes, L.gw_state_bytes.restype = [vp, C.POINTER(C.c_uint64)], C.c_int
+    L.gw_snapshot_bytes.argtypes, L.gw_snapshot_bytes.restype = [vp, C.POINTER(C.c_uint64)], C.c_int
+    L.gw_get_snapshot.argtypes, L.gw_get_snapshot.restype = [vp, vp, C.c_uint64], C.c_int
+    L.gw_set_state.argtypes, L.gw_set_state.restype = [vp, vp, C.c_uint64], C.c_int
     L.gw_link_info.argtypes = [vp, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.gw_link_info.restype = C.c_int
     L.gw_noise_states.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_double)]

@@ -60,7 +60,9 @@ struct gw_env {
     GwDevConst   cst_host;
     GwState      st;          // device pointers
     void*        blocks[32];  // every hipMalloc'd block, for gw_destroy
+    size_t       block_bytes[32];
     int          nblocks;
+    int          nblocks_create;   // blocks that exist since gw_create (later ones are scratch: gw_pack_feedback's counter)
     uint64_t     bytes;
     uint32_t*    pack_bad;    // device counter: elements gw_pack_feedback could not represent
     double       t_bound;     // upper bound of every env's simulated time (start + steps launched x step_max)
@@ -83,6 +85,7 @@ int dev_alloc(gw_env* env, T** out, size_t count)
         (void)hipFree(p);
         return fail(GW_ENOMEM, "internal: block table full");
     }
+    env->block_bytes[env->nblocks] = bytes;
     env->blocks[env->nblocks++] = p;
     env->bytes += bytes;
     *out = (T*)p;
@@ -554,6 +557,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     if (rc) { rc = fail(GW_EHIP, "init kernel launch failed"); gw_destroy(env); return rc; }
     HIP_TRY_D(hipDeviceSynchronize());
 #undef HIP_TRY_D
+    env->nblocks_create = env->nblocks;
     *out = env;
     return GW_OK;
 }
@@ -779,6 +783,87 @@ int gw_now_ptr(gw_env* env, const void** now_dev, int64_t* stride_bytes)
     if (!env || !now_dev || !stride_bytes) return fail(GW_EINVAL, "env/now/stride is NULL");
     if (env->st.tw) { *now_dev = env->st.tw; *stride_bytes = 16; }          // {now, next tick} records
     else { *now_dev = env->st.xw; *stride_bytes = 16; }                    // explicit-queue mode: the same record shape
+    return GW_OK;
+}
+
+// ---- checkpoint / restore (the reference cannot snapshot its SimPy generators; here an env's state is a
+// handful of arrays in HBM).  A snapshot is every device block the handle has held since gw_create, in allocation order, behind a
+// header that carries the configuration it belongs to.
+struct GwSnapHeader {
+    uint32_t magic, abi;
+    uint64_t total;
+    gw_config cfg;
+    int32_t nblocks, dyn;
+    uint64_t block_bytes[32];
+    double t_bound;
+};
+static const uint32_t kSnapMagic = 0x4e535747u;            // "GWSN"
+
+int gw_snapshot_bytes(gw_env* env, uint64_t* bytes)
+{
+    if (!env || !bytes) return fail(GW_EINVAL, "env/bytes is NULL");
+    uint64_t t = sizeof(GwSnapHeader);
+    for (int i = 0; i < env->nblocks_create; ++i) t += env->block_bytes[i];
+    *bytes = t;
+    return GW_OK;
+}
+
+int gw_get_snapshot(gw_env* env, void* dst, uint64_t bytes)
+{
+    if (!env || !dst) return fail(GW_EINVAL, "env/dst is NULL");
+    uint64_t need = 0;
+    int rc = gw_snapshot_bytes(env, &need);
+    if (rc) return rc;
+    if (bytes != need) return fail(GW_EINVAL, "snapshot needs %llu bytes, got %llu", (unsigned long long)need, (unsigned long long)bytes);
+    if ((rc = select_device(env))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    GwSnapHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = kSnapMagic; h.abi = GW_ABI_VERSION; h.total = need; h.cfg = env->cfg; h.nblocks = env->nblocks_create; h.dyn = env->dyn;
+    for (int i = 0; i < env->nblocks_create; ++i) h.block_bytes[i] = env->block_bytes[i];
+    h.t_bound = env->t_bound;
+    uint8_t* o = (uint8_t*)dst;
+    memcpy(o, &h, sizeof h);
+    o += sizeof h;
+    for (int i = 0; i < env->nblocks_create; ++i) {
+        HIP_TRY(hipMemcpy(o, env->blocks[i], env->block_bytes[i], hipMemcpyDeviceToHost));
+        o += env->block_bytes[i];
+    }
+    return GW_OK;
+}
+
+// Restore a snapshot into a handle created with the SAME gw_config (the same handle later on, or a fresh one -- on any GPU:
+// hip_device is not compared).  Every later step continues bit for bit as the snapshotted handle would have.
+int gw_set_state(gw_env* env, const void* src, uint64_t bytes)
+{
+    if (!env || !src) return fail(GW_EINVAL, "env/src is NULL");
+    if (bytes < sizeof(GwSnapHeader)) return fail(GW_EINVAL, "not a snapshot (too short)");
+    GwSnapHeader h;
+    memcpy(&h, src, sizeof h);
+    if (h.magic != kSnapMagic || h.abi != (uint32_t)GW_ABI_VERSION || h.total != bytes) return fail(GW_EINVAL, "not a snapshot of this ABI");
+    gw_config a = h.cfg, b = env->cfg;
+    a.hip_device = b.hip_device = 0;
+    if (memcmp(&a, &b, sizeof a) != 0 || h.nblocks != env->nblocks_create || h.dyn != env->dyn)
+        return fail(GW_EINVAL, "snapshot belongs to a handle with another configuration");
+    for (int i = 0; i < h.nblocks; ++i)
+        if (h.block_bytes[i] != env->block_bytes[i]) return fail(GW_EINVAL, "snapshot belongs to a handle with another layout");
+    int rc = select_device(env);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    const uint8_t* in = (const uint8_t*)src + sizeof h;
+    for (int i = 0; i < h.nblocks; ++i) {
+        HIP_TRY(hipMemcpy(env->blocks[i], in, env->block_bytes[i], hipMemcpyHostToDevice));
+        in += env->block_bytes[i];
+    }
+    // the header in front of the `ip` records holds THIS handle's device pointers: put them back
+    if (env->st.ip) {
+        uint8_t* blob = const_cast<uint8_t*>(env->st.blob);
+        const int D = env->st.D;
+        HIP_TRY(hipMemcpy(blob + gw_hdr_cst_off(D), &env->cst_host, sizeof env->cst_host, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(blob + gw_hdr_st_off(D), &env->st, sizeof env->st, hipMemcpyHostToDevice));
+    }
+    env->t_bound = h.t_bound > env->t_bound ? h.t_bound : env->t_bound;      // (an upper bound either way)
+    HIP_TRY(hipDeviceSynchronize());
     return GW_OK;
 }
 

@@ -282,4 +282,7 @@ int gw_launch_pack_feedback(int64_t count, int center, int pv, const int32_t* ob
 int gw_launch_unpack_feedback(int64_t count, int center, int pv, const uint8_t* packed, int32_t* obs, float* reward, uint8_t* done,
                               void* stream);
 
-#define GW_MAX_MULT        15          // packets per tick supported by the suffix encoding's ceil-div
+#define GW_MAX_MULT        100         // packets per tick in the suffix encoding = the handle-wide limit (the deque's capacity: more
+                                       // than 100 packets per tick only ever leaves the last 100 in the queue).  gw_ceil_div's
+                                       // reciprocal is exact for len <= 100 up to multiplicity 256 (checked exhaustively by
+                                       // tests/test_host_logic.py), the kernels' 24-bit multiplies far beyond.

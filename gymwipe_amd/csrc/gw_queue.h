@@ -32,7 +32,7 @@ struct GwTally { uint32_t app, pop, drop, tx, deliv; };
 
 GW_HD uint32_t gw_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-// ceil(len / mult) for len <= 255, mult <= GW_MAX_MULT, with inv16 = ceil(65536 / mult)
+// ceil(len / mult) for len <= GW_QUEUE_CAP, mult <= GW_MAX_MULT, with inv16 = ceil(65536 / mult) (exact up to mult 256)
 GW_HD uint32_t gw_ceil_div(uint32_t len, uint32_t mult, uint32_t inv16)
 {
     return ((len + mult - 1u) * inv16) >> 16;

@@ -65,7 +65,7 @@ class StepOutputs:
     contiguous tensors on the env's GPU.  Their device addresses are taken ONCE, here (a step is enqueued every few
     microseconds; four ``data_ptr()`` calls are 10 % of that), so the tensors must not be resized or re-pointed afterwards;
     the object keeps them alive."""
-    __slots__ = ("obs", "reward", "done", "feedback_bytes", "_ptrs", "_as_tuple")
+    __slots__ = ("obs", "reward", "done", "feedback_bytes", "_ptrs", "_as_tuple", "_dev")
 
     def __init__(self, obs, reward, done, feedback_bytes=None):
         torch = _torch()
@@ -79,6 +79,7 @@ class StepOutputs:
         self._ptrs = (obs.data_ptr(), reward.data_ptr(), done.data_ptr(),
                       feedback_bytes.data_ptr() if feedback_bytes is not None else 0)
         self._as_tuple = (obs, reward, done)
+        self._dev = obs.device.index or 0                 # step() refuses outputs that live on another GPU than the env
 
 
 class VecCounterTrafficEnv(BaseEnv):
@@ -278,7 +279,12 @@ class VecCounterTrafficEnv(BaseEnv):
         (torch tensors on the env's GPU are used in place).  Returns
         ``(obs int32[N], reward float32[N], done uint8[N], info)``; an action outside the action
         space flags its env (``check()`` raises) and leaves that env untouched.
-        ``out``: a ``StepOutputs`` to write this step's outputs into (instead of the env's own buffers)."""
+        ``out``: a ``StepOutputs`` to write this step's outputs into (instead of the env's own buffers).
+
+        Aliasing contract of the fast path: an action tensor OBJECT that passed validation once, and the tensors inside a
+        ``StepOutputs``, are taken at their word afterwards -- their device addresses, dtype, shape and device must not be
+        changed behind the env's back (``set_()``, ``resize_()``, swapping ``.data``); writing new VALUES into them is what
+        they are for.  A ``StepOutputs`` on another GPU than the env is refused."""
         # (this method is enqueued ~200 000 times a second: the common path -- pre-staged int32 tensors on this GPU, reused
         #  output buffers, the caller on this env's device -- is written out flat, without helper calls)
         dev = action["device"]
@@ -291,6 +297,8 @@ class VecCounterTrafficEnv(BaseEnv):
         if hit is None or hit() is not dur:
             dur = self._checked(dur, "duration")
         idx = self._dev_index
+        if out is not None and out._dev != idx:
+            raise ValueError("StepOutputs on cuda:%d passed to an env on cuda:%d" % (out._dev, idx))
         if out is not None and self._cuda_get_device() == idx and self._fast is not None and self._custom is None:
             p = out._ptrs                                       # preallocated outputs, addresses taken at construction
             if p[3]:
@@ -490,6 +498,21 @@ class VecCounterTrafficEnv(BaseEnv):
         b = C.c_uint64()
         nat.check(self._L.gw_state_bytes(self._h, C.byref(b)))
         return int(b.value)
+
+    def snapshot(self):
+        """Checkpoint: every byte of this env's device state as one uint8 numpy array (synchronises).  ``restore()`` puts it
+        back -- into this env later on, or into a fresh env created with the same arguments -- and every later step continues
+        bit for bit as this one would have (gw_get_snapshot / gw_set_state)."""
+        n = C.c_uint64()
+        nat.check(self._L.gw_snapshot_bytes(self._h, C.byref(n)))
+        out = np.empty(int(n.value), np.uint8)
+        nat.check(self._L.gw_get_snapshot(self._h, out.ctypes.data, out.nbytes))
+        return out
+
+    def restore(self, snap):
+        snap = np.ascontiguousarray(snap, dtype=np.uint8)
+        nat.check(self._L.gw_set_state(self._h, snap.ctypes.data, snap.nbytes))
+        self._seen.clear()
 
     def link_info(self, frm, to):
         a, p = C.c_double(), C.c_double()

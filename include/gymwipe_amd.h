@@ -214,11 +214,26 @@ int gw_received(gw_env* env, int32_t* out_dev, void* stream);
  *   GW_CFG_PER_ENV_GEOMETRY: "pos" f64[N][R][2] | "link_power" f64[N][R][R] (mW, from -> to) */
 int gw_get_state(gw_env* env, const char* field, void* dst_host, size_t bytes);
 
+/* Ranges of the event counts in the DEFAULT queue mode, where most of them are derived rather than counted (only popped,
+ * delivered, bad actions and flags are bumped on the device): steps = env.step() launches - bad actions; transmissions =
+ * steps + popped; appended = ticks * sum(multiplicity); dropped = appended - popped - queued.  `popped` and `delivered` of
+ * one env share a 64-bit word (popped in the low half): beyond 2^32 - 1 pops per env the carry would reach `delivered`; the
+ * tick counter is 32 bits (2^32 ticks = 49 days of simulated time at the reference's 1 ms interval).  Neither limit is
+ * checked; a handle that may get there should use GW_CFG_EXPLICIT_QUEUE | GW_CFG_PER_ENV_STATS (64-bit counts per event). */
 int gw_stats_read(gw_env* env, gw_stats* out);          /* synchronises the device */
 /* the sticky per-env flag words back to zero (gw_get_state "flags", gw_stats.flags_or), so that a later check tells
  * WHEN a condition arose; counters are untouched */
 int gw_clear_flags(gw_env* env, void* stream);
 int gw_state_bytes(gw_env* env, uint64_t* bytes);       /* HBM held by this handle */
+
+/* Checkpoint / restore.  The reference cannot snapshot a running simulation (SimPy generators; only the agent's weights are
+ * saved, agents/dqn_counter_traffic.py:73); here an env's state is a handful of arrays in HBM.  gw_get_snapshot copies all of it
+ * to host memory (gw_snapshot_bytes bytes; synchronises the device); gw_set_state restores it into a handle created with the
+ * same gw_config -- the same handle later on, or a fresh one on any GPU -- after which every step continues bit for bit as the
+ * snapshotted handle would have.  GW_EINVAL for a blob that is not a snapshot of this ABI / configuration. */
+int gw_snapshot_bytes(gw_env* env, uint64_t* bytes);
+int gw_get_snapshot(gw_env* env, void* dst_host, uint64_t bytes);
+int gw_set_state(gw_env* env, const void* src_host, uint64_t bytes);
 
 /* static link tables (host side, for tests): attenuation dB, rx power mW, thermal mW,
  * and the rx-power state machine used instead of per-env f64 noise state */

@@ -20,7 +20,7 @@ for it in range(COUNT):
     ang, rad = rng.uniform(0, 2 * np.pi, D), rng.uniform(0.4, 6.5, D)
     pos = [(float(r * np.cos(a)), float(r * np.sin(a))) for r, a in zip(rad, ang)]
     rrm = (float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-1.5, 1.5)))
-    mult = [int(m) for m in rng.choice([0, 1, 1, 2, 3, 5, 9, 15], D)]
+    mult = [int(m) for m in rng.choice([0, 1, 1, 2, 3, 5, 9, 15, 16, 37, 64, 100], D)]
     extra = {}
     for _ in range(int(rng.integers(0, 4))):
         a, b = sorted(int(x) for x in rng.choice(D + 1, 2, replace=False))

@@ -136,6 +136,23 @@ def test_event_totals_match_oracle(explicit):
     assert st["dropped"] == int(orc.get("n_dropped").sum())
 
 
+@pytest.mark.parametrize("D,mult,K", [(4, [100, 37, 1, 64], 40), (3, [16, 99, 7], 40), (2, [100, 100], 24), (16, [1, 3, 100, 15, 16, 17, 31, 32, 33, 50, 64, 99, 2, 5, 7, 0], 24)])
+def test_suffix_encoding_with_multiplicities_up_to_the_deques_capacity(D, mult, K):
+    """The default (suffix) queue encoding takes any multiplicity up to 100 (rounds 1-2: 15): step kernel, then the fused
+    rollout from the same state, against the oracle -- queue contents entry by entry."""
+    import torch
+    N = 1024
+    env, orc = _mk(N, D, multiplicity=mult)
+    dev, dur = action_stream(500 + D, K + 16, N, D)
+    _run(env, orc, dev[:K], dur[:K], reset_every=9, check_every=8)
+    obs, rew, done = env.rollout(torch.from_numpy(dev[K:]), torch.from_numpy(dur[K:]))
+    for k in range(16):
+        oo, orr, od = orc.step(dev[K + k], dur[K + k])
+        assert (obs[k].cpu().numpy() == oo).all() and (rew[k].cpu().numpy() == orr).all(), k
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
+    assert int(orc.get("n_dropped").min()) > 0
+
+
 @pytest.mark.parametrize("D,mult", [(32, None), (4, [100, 37, 1, 64]), (3, [16, 99, 7])])
 def test_generic_kernel_heavy_appends_totals_and_queues(D, mult):
     """Explicit-ring kernel with the most appends a step can make: every duration 19 (20 ticks per step) at D = 32,
@@ -761,3 +778,94 @@ def test_loader_picks_the_build_that_matches_the_devices_xnack_mode():
         pytest.skip("GW_LIB set")
     assert picked == ("libgymwipe_amd_xnackoff.so" if "xnack-" in arch else "libgymwipe_amd.so"), (arch, picked)
     assert nat.lib()._name.endswith(picked)
+
+
+@pytest.mark.parametrize("kw", [{}, {"explicit_queue": True, "per_env_stats": True}, {"per_env_geometry": True}], ids=["suffix", "explicit", "per-env-geometry"])
+def test_snapshot_and_restore_continue_bit_for_bit(kw):
+    """gw_get_snapshot / gw_set_state: a handle rewound to a snapshot, and a FRESH handle given the snapshot, both continue
+    exactly as the original did -- every output of every later step and the final state (checkpoint / resume, SURVEY
+    section 5; the reference can only save its agent's weights)."""
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv
+    N, D, K1, K2 = 2048, 4, 30, 40
+    dev, dur = action_stream(77, K1 + K2, N, D)
+    mk = lambda: VecCounterTrafficEnv(N, num_devices=D, **kw)
+    env = mk()
+    if kw.get("per_env_geometry"):
+        rng = np.random.default_rng(3)
+        pos = np.zeros((N, D + 1, 2)); pos[:, :D] = rng.uniform(-3, 3, (N, D, 2))
+        env.set_positions(pos)
+    step = lambda e, k: e.step({"device": torch.from_numpy(dev[k]), "duration": torch.from_numpy(dur[k])})
+    env.reset()
+    for k in range(K1):
+        if k == 17:
+            env.reset(torch.from_numpy((np.arange(N) % 3 == 0).astype(np.uint8)))
+        step(env, k)
+    snap = env.snapshot()
+    fields = ("now", "wake", "counter", "qlen", "queue", "received", "last_abs", "rx_power", "flags", "n_tx", "n_delivered", "n_popped", "n_dropped")
+
+    def run_on(e):
+        outs = []
+        for k in range(K1, K1 + K2):
+            if k == K1 + 11:
+                e.reset()
+            o, r, d_, _ = step(e, k)
+            outs.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d_.cpu().numpy().copy()))
+        return outs, {f: e.get_state(f) for f in fields}
+
+    ref_out, ref_state = run_on(env)
+    env.restore(snap)                                             # the same handle, rewound
+    again_out, again_state = run_on(env)
+    fresh = mk()                                                  # a new handle with the same configuration
+    fresh.restore(snap)
+    fresh_out, fresh_state = run_on(fresh)
+    for got_out, got_state, who in ((again_out, again_state, "rewound handle"), (fresh_out, fresh_state, "fresh handle")):
+        for k in range(K2):
+            for a, b in zip(ref_out[k], got_out[k]):
+                assert (a == b).all(), (who, k)
+        for f in fields:
+            assert (ref_state[f].view(np.uint8) == got_state[f].view(np.uint8)).all(), (who, f)
+    other = VecCounterTrafficEnv(N, num_devices=D, multiplicity=[1, 1, 1, 1], **kw)   # another configuration refuses it
+    with pytest.raises(Exception):
+        other.restore(snap)
+
+
+def test_derived_event_counts_equal_counted_ones():
+    """Default mode derives most event counts from the state (steps = launches - bad, transmissions = steps + popped,
+    appended = ticks x sum(mult), dropped = appended - popped - queued); the explicit-queue handle with
+    GW_CFG_PER_ENV_STATS counts every event.  Same actions -- bad ones included --, masked resets, a hipGraph replay."""
+    import torch
+    from gymwipe_amd import VecCounterTrafficEnv
+    N, D, K = 1024, 4, 48
+    a = VecCounterTrafficEnv(N, num_devices=D)
+    b = VecCounterTrafficEnv(N, num_devices=D, explicit_queue=True, per_env_stats=True)
+    dev, dur = action_stream(91, K, N, D)
+    dev[5, ::7] = D + 2                                            # actions outside the action space
+    dur[9, ::11] = 25
+    rng = np.random.default_rng(1)
+    a.reset(); b.reset()
+    g_dev = torch.zeros(N, dtype=torch.int32, device="cuda"); g_dur = torch.zeros(N, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    for k in range(K):
+        if k % 13 == 6:
+            m = torch.from_numpy((rng.random(N) < 0.3).astype(np.uint8))
+            a.reset(m); b.reset(m)
+        act = {"device": torch.from_numpy(dev[k]).cuda(), "duration": torch.from_numpy(dur[k]).cuda()}
+        if k == 20:                                                # this step of `a` runs as a captured launch, replayed once
+            g_dev.copy_(act["device"]); g_dur.copy_(act["duration"])
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                a.step({"device": g_dev, "duration": g_dur})
+            graph.replay()
+        else:
+            a.step(act)
+        b.step(act)
+    torch.cuda.synchronize()
+    for f in ("n_tx", "n_delivered", "n_appended", "n_popped", "n_dropped", "flags"):
+        x, y = a.get_state(f), b.get_state(f)
+        assert (x == y).all(), f
+    sa, sb = a.stats(), b.stats()
+    for key in ("steps", "transmissions", "delivered", "appended", "popped", "dropped", "bad_actions"):
+        assert sa[key] == sb[key], key
+    assert sa["bad_actions"] > 0

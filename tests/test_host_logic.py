@@ -56,7 +56,17 @@ def test_config_default_matches_reference_constants(native_lib):
     assert b"num_devices" in native_lib.gw_last_error()
 
 
-@pytest.mark.parametrize("mult,bound", [(1, 65536), (3, 65536), (3, 40), (2, 7), (15, 1), (5, 300)])
+def test_suffix_encoding_ceil_div_is_exact_for_every_multiplicity():
+    """gw_ceil_div (gw_queue.h): ((len + mult - 1) * ceil(65536 / mult)) >> 16 == ceil(len / mult) for every queue length
+    0..100 and every multiplicity the handle accepts (1..100) -- and beyond, up to 256."""
+    for m in range(1, 257):
+        inv16 = (65536 + m - 1) // m
+        for ln in range(0, 101):
+            assert ((ln + m - 1) * inv16) >> 16 == (ln + m - 1) // m, (m, ln)
+
+
+@pytest.mark.parametrize("mult,bound", [(1, 65536), (3, 65536), (3, 40), (2, 7), (15, 1), (5, 300), (16, 65536), (37, 65536),
+                                        (64, 9), (99, 300), (100, 65536)])
 def test_queue_encoding_fuzz_against_explicit_deque(native_lib, mult, bound):
     """gw_queue.h (the code the kernel runs) vs deque(maxlen=100): ticks, resets, pops."""
     for seed in range(3):
@@ -82,7 +92,9 @@ def test_fast_paths_validate_for_default_configs(native_lib):
     cfg.code_rate, cfg.max_ber = 0.5, 0.11                # integer decode shortcut must switch itself off
     assert native_lib.gw_selftest_fastmath(C.byref(cfg), None) & 4 == 0
     cfg = _native.default_config(16, 4)
-    cfg.mult[1] = 99                                      # suffix encoding supports mult <= 15
+    cfg.mult[1] = 99                                      # up to the deque's capacity in both queue encodings (rounds 1-2: 15)
+    assert native_lib.gw_selftest_fastmath(C.byref(cfg), None) == 31
+    cfg.mult[1] = 101
     assert native_lib.gw_selftest_fastmath(C.byref(cfg), None) < 0
 
 

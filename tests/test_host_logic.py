@@ -210,7 +210,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu(native_lib):
                          (lambda c: setattr(c, "slot", 0.0), b"slot"),
                          (lambda c: setattr(c, "flags", nat.CFG_PEER_RECEIVE), b"EXPLICIT_QUEUE"),
                          (lambda c: c.extra_att_db[0].__setitem__(1, 3.0), b"symmetric"),
-                         (lambda c: c.mult.__setitem__(0, 40), b"EXPLICIT_QUEUE")):
+                         (lambda c: c.mult.__setitem__(0, 101), b"mult")):                       # (<= 100 in both queue encodings)
         cfg = nat.default_config(64, 4)
         mutate(cfg)
         rc = L.gw_create(C.byref(cfg), C.byref(h))

@@ -265,13 +265,14 @@ class VecCounterTrafficEnv(BaseEnv):
         that passed once is not re-validated (a caller steps with the same pre-staged tensors again and again; dtype, device
         and shape of a tensor object do not change under ordinary use): one dict probe instead of seven attribute tests."""
         hit = self._seen.get(id(t))
-        if hit is not None and hit() is t:
+        if hit is not None and hit[0]() is t:
             return t
         if not self._ready(t):
             return self._as_i32(t, name)
         if len(self._seen) >= 8192:
             self._seen.clear()
-        self._seen[id(t)] = weakref.ref(t)                   # weak: the env must not keep a caller's action buffers alive
+        # weak: the env must not keep a caller's action buffers alive; the device address is taken once, with the validation
+        self._seen[id(t)] = (weakref.ref(t), t.data_ptr())
         return t
 
     def step(self, action, out=None):
@@ -291,20 +292,26 @@ class VecCounterTrafficEnv(BaseEnv):
         dur = action["duration"]
         seen = self._seen
         hit = seen.get(id(dev))
-        if hit is None or hit() is not dev:
+        if hit is None or hit[0]() is not dev:
             dev = self._checked(dev, "device")
+            dev_ptr = dev.data_ptr()
+        else:
+            dev_ptr = hit[1]
         hit = seen.get(id(dur))
-        if hit is None or hit() is not dur:
+        if hit is None or hit[0]() is not dur:
             dur = self._checked(dur, "duration")
+            dur_ptr = dur.data_ptr()
+        else:
+            dur_ptr = hit[1]
         idx = self._dev_index
         if out is not None and out._dev != idx:
             raise ValueError("StepOutputs on cuda:%d passed to an env on cuda:%d" % (out._dev, idx))
         if out is not None and self._cuda_get_device() == idx and self._fast is not None and self._custom is None:
             p = out._ptrs                                       # preallocated outputs, addresses taken at construction
             if p[3]:
-                rc = self._fast.step_fb(self._hv, dev.data_ptr(), dur.data_ptr(), p[0], p[1], p[2], p[3], self._cuda_raw_stream(idx))
+                rc = self._fast.step_fb(self._hv, dev_ptr, dur_ptr, p[0], p[1], p[2], p[3], self._cuda_raw_stream(idx))
             else:
-                rc = self._fast.step(self._hv, dev.data_ptr(), dur.data_ptr(), p[0], p[1], p[2], self._cuda_raw_stream(idx))
+                rc = self._fast.step(self._hv, dev_ptr, dur_ptr, p[0], p[1], p[2], self._cuda_raw_stream(idx))
             if rc:
                 nat.check(rc)
             self._last = out._as_tuple
@@ -321,18 +328,18 @@ class VecCounterTrafficEnv(BaseEnv):
             fast = self._fast                                   # CPython fast-call shim (csrc/gw_pyfast.c) when built
             if fb is not None:
                 rc = (fast.step_fb if fast is not None else self._L.gw_step_fb)(
-                    self._hv, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), fb.data_ptr(),
+                    self._hv, dev_ptr, dur_ptr, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), fb.data_ptr(),
                     self._cuda_raw_stream(idx))
             elif fast is not None:
-                rc = fast.step(self._hv, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                rc = fast.step(self._hv, dev_ptr, dur_ptr, obs.data_ptr(), rew.data_ptr(),
                                done.data_ptr(), self._cuda_raw_stream(idx))
             else:
-                rc = self._L.gw_step(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                rc = self._L.gw_step(self._h, dev_ptr, dur_ptr, obs.data_ptr(), rew.data_ptr(),
                                      done.data_ptr(), self._cuda_raw_stream(idx))
         else:
             torch = _torch()
             with torch.cuda.device(self.device):
-                rc = self._L.gw_step_fb(self._h, dev.data_ptr(), dur.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                rc = self._L.gw_step_fb(self._h, dev_ptr, dur_ptr, obs.data_ptr(), rew.data_ptr(),
                                         done.data_ptr(), fb.data_ptr() if fb is not None else None, self._stream())
         if rc:
             nat.check(rc)

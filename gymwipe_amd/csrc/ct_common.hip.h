@@ -6,6 +6,22 @@
 #include "gw_queue.h"
 #include "gw_fastmath.h"
 
+// In-kernel stamps: only in the diagnostic build (make STAMPS=1 -> libgymwipe_amd_stamps.so); the
+// product library contains no stamp code.  Values go to a buffer nothing else reads.
+#ifdef GW_STAMPS
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long _t;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if ((threadIdx.x & 63) == 0)                                                          \
+            st.stamps[(((size_t)blockIdx.x * ((blockDim.x + 63) >> 6)) + (threadIdx.x >> 6)) * 16 + (i)] = _t; \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace gwk {
 
 typedef GwTally Tally;
@@ -218,32 +234,53 @@ __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 l
 // Now: the per-lane counters go into seven words summed by LDS atomics (one ds_add per word for the whole
 // wave), and lanes 0..7 issue ONE global atomic instruction on the wave's line.  Appends and drops get a full
 // 32-bit word each (64 lanes x 21 ticks x multiplicity 100 = 134 400 per wave does not fit 16 bits).
+// sum / OR over the wave's 64 lanes on the DPP path (result in lane 63): an inclusive scan within each row of 16 lanes
+// (row_shr 1, 2, 4, 8; lanes shifted in from outside the row contribute 0), then the row totals carried across rows
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six VALU instructions per word -- the LDS atomics this
+// replaces serialise over the lanes of a wave when they all hit one address: 7 words took 2 700 cycles (in-kernel stamps).
+template <int CTRL, int ROW_MASK, bool OR>
+__device__ __forceinline__ uint32_t gw_dpp_step(uint32_t v)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return OR ? (v | o) : (v + o);
+}
+template <bool OR>
+__device__ __forceinline__ uint32_t gw_wave_total(uint32_t v)
+{
+    v = gw_dpp_step<0x111, 0xf, OR>(v);
+    v = gw_dpp_step<0x112, 0xf, OR>(v);
+    v = gw_dpp_step<0x114, 0xf, OR>(v);
+    v = gw_dpp_step<0x118, 0xf, OR>(v);
+    v = gw_dpp_step<0x142, 0xa, OR>(v);
+    v = gw_dpp_step<0x143, 0xc, OR>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// (called by every lane of the wave, converged)
 __device__ __forceinline__ void publish_totals(unsigned long long* totals, const Tally& k, uint32_t k_steps,
                                                uint32_t k_bad, uint32_t fl_new)
 {
-    __shared__ uint32_t s_acc[4][8];                    // [wave in block][word]
-    const uint32_t lane = threadIdx.x & 63u, wv = (threadIdx.x >> 6) & 3u;
-    if (lane < 8u) s_acc[wv][lane] = 0u;                // same wave, in-order LDS: no barrier needed
     // every event count gets a full 32-bit word (a lane can pop hundreds of packets per step at a high bit rate);
     // steps, bad <= 64 each share one
-    atomicAdd(&s_acc[wv][GW_T_TX], k.tx);
-    atomicAdd(&s_acc[wv][GW_T_DELIV], k.deliv);
-    atomicAdd(&s_acc[wv][GW_T_POP], k.pop);
-    atomicAdd(&s_acc[wv][GW_T_APP], k.app);
-    atomicAdd(&s_acc[wv][GW_T_DROP], k.drop);
-    atomicAdd(&s_acc[wv][GW_T_STEPS], k_steps | (k_bad << 8));
-    atomicOr(&s_acc[wv][GW_T_FLAGS], fl_new);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w_tx = gw_wave_total<false>(k.tx), w_deliv = gw_wave_total<false>(k.deliv), w_pop = gw_wave_total<false>(k.pop);
+    const uint32_t w_app = gw_wave_total<false>(k.app), w_drop = gw_wave_total<false>(k.drop);
+    const uint32_t w_sb = gw_wave_total<false>(k_steps | (k_bad << 8));
+    const uint32_t w_fl = gw_wave_total<true>(fl_new);
     if (lane < (uint32_t)GW_T_COUNT) {
-        const uint32_t w = s_acc[wv][lane == (uint32_t)GW_T_BAD ? (uint32_t)GW_T_STEPS : lane];
-        unsigned long long v = w;
-        if (lane == (uint32_t)GW_T_STEPS) v = w & 0xffu;
-        if (lane == (uint32_t)GW_T_BAD) v = w >> 8;
-        const uint32_t f = w;
+        uint32_t w = w_sb & 0xffu;                                   // GW_T_STEPS
+        w = lane == (uint32_t)GW_T_TX ? w_tx : w;
+        w = lane == (uint32_t)GW_T_DELIV ? w_deliv : w;
+        w = lane == (uint32_t)GW_T_APP ? w_app : w;
+        w = lane == (uint32_t)GW_T_POP ? w_pop : w;
+        w = lane == (uint32_t)GW_T_DROP ? w_drop : w;
+        w = lane == (uint32_t)GW_T_FLAGS ? w_fl : w;
+        w = lane == (uint32_t)GW_T_BAD ? (w_sb >> 8) : w;
         const size_t waves_per_block = (blockDim.x + 63) >> 6;
         const size_t wave = (size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
         unsigned long long* t = totals + wave * GW_T_COUNT;
-        if (lane == GW_T_FLAGS) { if (f) atomicOr(&t[GW_T_FLAGS], (unsigned long long)f); }
-        else if (v) atomicAdd(&t[lane], v);
+        if (lane == GW_T_FLAGS) { if (w) atomicOr(&t[GW_T_FLAGS], (unsigned long long)w); }
+        else if (w) atomicAdd(&t[lane], (unsigned long long)w);
     }
 }
 

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
     const uint8_t* g_h2 = st.blob + L.h2;                                      // j after the announcement and >= 1 packet of d (idem)
     const uint8_t* s_cls = s_blob + L.cls;
 
+    STAMP(0);
     Tally k = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, k_steps = 0, fl_new = 0;
 
@@ -95,8 +96,22 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
 #pragma unroll
     for (int w = 0; w < NXW; ++w) xsw[w] = DT > 0 ? reinterpret_cast<const uint4*>(st.xs + (size_t)el * st.XB)[w] : make_uint4(0u, 0u, 0u, 0u);
     const int d = device[el];
-    const int du = duration[el];
+    int du = duration[el];
     __syncthreads();
+    // every load issued above has LANDED before the walk branches (opaque uses: the compiler waits here).  Without this the
+    // bad-action path reaches the kernel's tail with those loads formally outstanding, the tail reuses their registers, and
+    // the wait the compiler then places at the join -- vmcnt counts loads and stores in one order -- makes the GOOD path
+    // sit out its own record stores before the totals (in-kernel stamps: 2 700 cycles)
+#define GW_LANDED(x) asm volatile("" : "+v"(x))
+    if (DT > 0) {
+#pragma unroll
+        for (int i = 0; i < DR; ++i) { GW_LANDED(qr[i].x); GW_LANDED(qr[i].y); GW_LANDED(qr[i].z); GW_LANDED(qr[i].w); }
+#pragma unroll
+        for (int w = 0; w < NXW; ++w) { GW_LANDED(xsw[w].x); GW_LANDED(xsw[w].y); GW_LANDED(xsw[w].z); GW_LANDED(xsw[w].w); }
+    }
+    GW_LANDED(du);
+#undef GW_LANDED
+    STAMP(1);
     // noise state of radio j (run-time j): from the record's registers (DT > 0) or from memory
     auto xs_get = [&](int j) -> uint8_t {
         if (DT > 0) {
@@ -116,6 +131,20 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
         return st.xs[(size_t)e * st.XB + j];
     };
 
+    // What the step leaves behind is held in registers and STORED AT THE VERY END, behind the wave's totals: the tail of the
+    // kernel reuses registers, and a register that is the data of a store in flight is not free before that store has
+    // completed (the compiler waits on vmcnt) -- with the stores first, the totals sat out a full store round trip.
+    bool out_good = false, out_bad = false;
+    int32_t out_obs = 0;
+    float out_rew = 0.0f;
+    uint8_t out_dn = 0;
+    GwRec qout[DR];
+    double2 out_xw = make_double2(0.0, 0.0);
+    uint4 out_xc = make_uint4(0u, 0u, 0u, 0u);
+    uint4 out_xs[NXW];
+    uint32_t out_xs_dirty = 0u;
+    Tally out_pe = {0, 0, 0, 0, 0};
+
     if (e < N) {
         uint32_t fl = xc0.w;
         uint32_t rvm = xc0.y;
@@ -128,10 +157,10 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             fl |= GW_FLAG_BADACT;
             k_bad = 1;
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
-            obs[e] = latest + c.counter_bound;
-            reward[e] = 0.0f;
-            done[e] = dn;
-            if (fl != xc0.w) st.xc[(size_t)e * 4 + 3] = fl;
+            out_bad = true;
+            out_obs = latest + c.counter_bound;
+            out_dn = dn;
+            out_xc = make_uint4(xc0.x, xc0.y, xc0.z, fl);
         } else {
             k_steps = 1;
             const StepMath m(c);
@@ -147,6 +176,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const uint32_t ctr0 = xc0.x;
             const int slots = du * c.duration_factor;                     // counter_traffic.py:149
 
+            STAMP(2);
             // ---- A.1 / A.2: announcement ---------------------------------------------
             const int La = ndigits(slots) + (c.float_duration ? 2 : 0);  // len(str(10000.0)) == len("10000") + 2
             const double pd_a = m.over_rate((double)(La * 8));
@@ -176,6 +206,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             const double t_r = an.t_e;
             const double t_end = t_r + (double)(slots + 1) * slot;       // simple_stack.py:557-558
 
+            STAMP(3);
             // ---- A.3: window at sender d -----------------------------------------------
             GwRec qr_d = {0u, 0u, 0u, 0u};
             if (DT > 0) {
@@ -275,6 +306,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 }
             };
 
+            STAMP(4);
             if (granted) {
                 const double total = (double)slots * slot;               // simple_stack.py:400
                 const double stopw = t_r + total;                        // :401 (== timeout time :406)
@@ -346,12 +378,13 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 }
             }
 
+            STAMP(5);
             // ---- A.5: remaining ticks up to the end of the step ----------------------------
             ticks_upto(t_end, true);
             // the same n_ticks ticks d's walk just counted reach every other sender's queue (all senders tick together); the
             // records are STORED at the very end of the step, behind every load (see above)
+            STAMP(6);
             const GwRec rec_d = store_q(rd);
-            GwRec qout[DR];
             if (DT > 0) {
 #pragma unroll
                 for (int i = 0; i < DR; ++i) {
@@ -378,6 +411,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 }
                 st.qrec[(int64_t)d * N + e] = rec_d;
             }
+            STAMP(7);
             uint32_t ctr_new = ctr0 + n_ticks;                            // `if counter < bound: counter += 1` per tick
             ctr_new = (ctr0 >= bound) ? ctr0 : (ctr_new < bound ? ctr_new : bound);
 
@@ -441,8 +475,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                         o.y = nbx[b + 4] | (nbx[b + 5] << 8) | (nbx[b + 6] << 16) | (nbx[b + 7] << 24);
                         o.z = nbx[b + 8] | (nbx[b + 9] << 8) | (nbx[b + 10] << 16) | (nbx[b + 11] << 24);
                         o.w = nbx[b + 12] | (nbx[b + 13] << 8) | (nbx[b + 14] << 16) | (nbx[b + 15] << 24);
-                        if (o.x != xsw[w].x || o.y != xsw[w].y || o.z != xsw[w].z || o.w != xsw[w].w)
-                            reinterpret_cast<uint4*>(st.xs + (size_t)e * st.XB)[w] = o;
+                        out_xs[w] = o;
+                        if (o.x != xsw[w].x || o.y != xsw[w].y || o.z != xsw[w].z || o.w != xsw[w].w) out_xs_dirty |= 1u << w;
                     }
                 } else {
                     uint8_t* xr = st.xs + (size_t)e * st.XB;
@@ -455,34 +489,52 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 }
             }
 
+            STAMP(8);
             // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -------
             const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
             const int32_t abs_d = latest < 0 ? -latest : latest;
             int32_t r = last_abs - abs_d;
             last_abs = abs_d;
             r = r > 10 ? 10 : (r < -10 ? -10 : r);
-            obs[e] = latest + c.counter_bound;
-            reward[e] = (float)r;
-            done[e] = dn;
-
-            if (DT > 0) {
-#pragma unroll
-                for (int i = 0; i < DR; ++i) st.qrec[(int64_t)i * N + e] = qout[i];
-            }
-            reinterpret_cast<double2*>(st.xw)[e] = make_double2(t_end, wake);
-            reinterpret_cast<uint4*>(st.xc)[e] = make_uint4(ctr_new, rvm, (uint32_t)last_abs | ((uint32_t)dn << 31), fl);
-            if (PER_ENV_STATS) {
-                st.pe_stats[0 * N + e] += k.tx;
-                st.pe_stats[1 * N + e] += k.deliv;
-                st.pe_stats[2 * N + e] += k.app;
-                st.pe_stats[3 * N + e] += k.pop;
-                st.pe_stats[4 * N + e] += k.drop;
-            }
+            out_good = true;
+            out_obs = latest + c.counter_bound;
+            out_rew = (float)r;
+            out_dn = dn;
+            out_xw = make_double2(t_end, wake);
+            out_xc = make_uint4(ctr_new, rvm, (uint32_t)last_abs | ((uint32_t)dn << 31), fl);
+            out_pe = k;
         }
         fl_new = fl;
     }
-
+    STAMP(9);
     publish_totals(st.totals, k, k_steps, k_bad, fl_new);
+    STAMP(10);
+    // ---- the step's stores, last of all ----------------------------------------------------------------------------
+    if (out_good || out_bad) {
+        obs[e] = out_obs;
+        reward[e] = out_rew;
+        done[e] = out_dn;
+    }
+    if (out_bad && out_xc.w != xc0.w) st.xc[(size_t)e * 4 + 3] = out_xc.w;
+    if (out_good) {
+        if (DT > 0) {
+#pragma unroll
+            for (int w = 0; w < NXW; ++w)
+                if ((out_xs_dirty >> w) & 1u) reinterpret_cast<uint4*>(st.xs + (size_t)e * st.XB)[w] = out_xs[w];
+#pragma unroll
+            for (int i = 0; i < DR; ++i) st.qrec[(int64_t)i * N + e] = qout[i];
+        }
+        reinterpret_cast<double2*>(st.xw)[e] = out_xw;
+        reinterpret_cast<uint4*>(st.xc)[e] = out_xc;
+        if (PER_ENV_STATS) {
+            st.pe_stats[0 * N + e] += out_pe.tx;
+            st.pe_stats[1 * N + e] += out_pe.deliv;
+            st.pe_stats[2 * N + e] += out_pe.app;
+            st.pe_stats[3 * N + e] += out_pe.pop;
+            st.pe_stats[4 * N + e] += out_pe.drop;
+        }
+    }
+    STAMP(11);
 }
 
 // fresh env: counters 1 (counter_traffic.py:48), first tick at t=0, all radios at thermal noise

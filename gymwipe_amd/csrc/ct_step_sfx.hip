@@ -24,21 +24,7 @@
 
 using namespace gwk;
 
-// In-kernel stamps: only in the diagnostic build (make STAMPS=1 -> libgymwipe_amd_stamps.so); the
-// product library contains no stamp code.  Values go to a buffer nothing else reads.
-#ifdef GW_STAMPS
-#define STAMP(i)                                                                              \
-    do {                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        unsigned long long _t;                                                                \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");            \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        if ((threadIdx.x & 63) == 0)                                                          \
-            st.stamps[(((size_t)blockIdx.x * ((blockDim.x + 63) >> 6)) + (threadIdx.x >> 6)) * 16 + (i)] = _t; \
-    } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
+// (in-kernel stamps of the diagnostic build: STAMP in ct_common.hip.h)
 
 namespace {
 

@@ -78,9 +78,40 @@ GW_HD void gw_run_advance(GwRun& r, uint32_t t, uint32_t mult, uint32_t inv20, u
     r.v0 = v < cap ? v : cap;
 }
 
+// drop the first t packets of a run, as selects (t == 0 changes nothing; a literal run only counts down)
+GW_HD void gw_run_advance_sel(GwRun& r, uint32_t t, uint32_t mult, uint32_t inv20, uint32_t cap)
+{
+    const uint32_t jj = r.j + t;
+    const uint32_t q = r.lit ? 0u : (jj * inv20) >> 20;
+    const uint32_t v = r.v0 + q;
+    r.n -= t;
+    r.j = r.lit ? r.j : jj - q * mult;
+    r.v0 = r.lit ? r.v0 : (v < cap ? v : cap);
+}
+
+// remove `count` packets from the head while NO run waits in the ring (M == 0: the queue is its head run, or head + tail):
+// straight-line, nothing but selects.  On the GPU every `if` of the general form below is an exec-mask region of its own
+// (three scalar instructions and, in this kernel, a scalar-register reload), and a wave with one lane per env runs them
+// all: in-kernel stamps put one call of the general form at ~1 000 cycles.
+GW_HD void gw_runq_pop_front_m0(GwRunQ& q, uint32_t count, uint32_t mult, uint32_t inv20, uint32_t cap)
+{
+    q.len -= count;
+    const uint32_t t1 = count < q.H.n ? count : q.H.n;
+    gw_run_advance_sel(q.H, t1, mult, inv20, cap);
+    const uint32_t rem = count - t1;
+    const bool used_up = count != 0u && q.H.n == 0u;     // head run used up: the tail moves up (or the queue is empty)
+    const bool two = q.state == 2u;
+    q.H.v0 = (used_up && two) ? q.T.v0 : q.H.v0;  q.H.n = (used_up && two) ? q.T.n : q.H.n;
+    q.H.j = (used_up && two) ? q.T.j : q.H.j;    q.H.lit = (used_up && two) ? q.T.lit : q.H.lit;
+    q.state = used_up ? (two ? 1u : 0u) : q.state;
+    gw_run_advance_sel(q.H, rem, mult, inv20, cap);      // rem != 0 only after the move (count <= len)
+    q.state = (rem != 0u && q.H.n == 0u) ? 0u : q.state;
+}
+
 // remove `count` packets from the head (window pops, drop-oldest); count <= len
 GW_HD void gw_runq_pop_front(GwRunQ& q, uint32_t count, uint64_t* ring, uint32_t mult, uint32_t inv20, uint32_t cap)
 {
+    if (q.M == 0u) { gw_runq_pop_front_m0(q, count, mult, inv20, cap); return; }
     q.len -= count;
     while (count > 0u) {
         const uint32_t t = count < q.H.n ? count : q.H.n;
@@ -175,10 +206,31 @@ GW_HD void gw_runq_ticks(GwRunQ& q, uint32_t k, uint32_t c, uint32_t bound, uint
     const uint32_t cap = base_bytes + bound;
     const uint32_t want = q.len + add;
     const uint32_t drops = want > (uint32_t)GW_QUEUE_CAP ? want - (uint32_t)GW_QUEUE_CAP : 0u;
-    gw_runq_append_counter(q, add, base_bytes + (c < bound ? c : bound), ring, mult, inv20, cap);
-    if (drops) gw_runq_pop_front(q, drops, ring, mult, inv20, cap);
+    const uint32_t v = base_bytes + (c < bound ? c : bound);
     t.app += add;
     t.drop += drops;
+    // ---- the usual case, straight-line: nothing waits in the ring and the append does not put anything there (it extends
+    //      the last run, or starts the queue's first or second run) ----
+    const bool none = q.state == 0u, one = q.state == 1u;
+    const uint32_t lv0 = one ? q.H.v0 : q.T.v0, ln = one ? q.H.n : q.T.n, lj = one ? q.H.j : q.T.j, llit = one ? q.H.lit : q.T.lit;
+    const uint32_t e = lj + ln;
+    const uint32_t qq = (e * inv20) >> 20;
+    const uint32_t nv = lv0 + qq;
+    const bool cont = !none && !llit && e - qq * mult == 0u && (nv < cap ? nv : cap) == v;   // the tick continues the last run
+    if (q.M == 0u && (cont || q.state != 2u)) {
+        const bool to_h = none || (one && cont), to_t = !none && !(one && cont);            // which slot the packets go to
+        const bool fresh = !cont;                                                            // ... as a new run
+        q.H.v0 = (to_h && fresh) ? v : q.H.v0;   q.H.j = (to_h && fresh) ? 0u : q.H.j;   q.H.lit = (to_h && fresh) ? 0u : q.H.lit;
+        q.H.n = to_h ? (fresh ? add : q.H.n + add) : q.H.n;
+        q.T.v0 = (to_t && fresh) ? v : q.T.v0;   q.T.j = (to_t && fresh) ? 0u : q.T.j;   q.T.lit = (to_t && fresh) ? 0u : q.T.lit;
+        q.T.n = to_t ? (fresh ? add : q.T.n + add) : q.T.n;
+        q.state = none ? 1u : ((one && !cont) ? 2u : q.state);
+        q.len = want;
+        gw_runq_pop_front_m0(q, drops, mult, inv20, cap);
+        return;
+    }
+    gw_runq_append_counter(q, add, v, ring, mult, inv20, cap);
+    if (drops) gw_runq_pop_front(q, drops, ring, mult, inv20, cap);
 }
 
 // host: the queue's packets, head first (out has room for GW_QUEUE_CAP); returns the length

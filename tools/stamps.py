@@ -14,11 +14,17 @@ N, D = 65536, int(os.environ.get("STAMPS_D", "4"))
 # windows; right after t = 0 the tick jump declines at every binade end and the plain loop shows up instead), the shared
 # counter-based action stream, a reset every W + K steps, stamps taken on the timed indices only
 W, K = int(os.environ.get("STAMPS_W", "5")), int(os.environ.get("STAMPS_K", "20"))
-env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, start_time=float(os.environ.get("STAMPS_T0", "300.0")))
+EXPLICIT = os.environ.get("STAMPS_EXPLICIT", "0") == "1"        # the generic kernel (ct_step.hip) instead of the default one
+env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, start_time=float(os.environ.get("STAMPS_T0", "300.0")),
+                                       explicit_queue=EXPLICIT, per_env_stats=EXPLICIT)
 a_dev, a_dur = actions_torch(1234, 0, N, 0, W + K, D, device="cuda")
 names = ["0 issue table+state loads, write LDS", "1 barrier", "2 state landed (touch ip)", "3 unpack, LDS lookups, consts",
          "4 announcement tx_times", "5 announcement decode, t_end", "6 window loop", "7 tail ticks_to(t_end)",
          "8 other senders + pack", "9 qb store", "10 feedback + stores", "11 counters store"]
+if EXPLICIT:
+    names = ["0 issue table+state loads, write LDS, barrier", "1 bad-action test, constants", "2 announcement", "3 queue record, lookups, prefetch",
+             "4 window loop", "5 tail ticks", "6 other senders' queues", "7 noise states", "8 feedback values", "9 totals", "10 all stores"]
+NS = len(names) + 1
 rows = []
 pops_rows = []
 prev_pop = env.get_state("n_popped").astype(np.int64)
@@ -33,7 +39,7 @@ for k in range(3 * (W + K)):
         out = np.empty((n_slots, 16), np.uint64)
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         w = out[: N // 64].astype(np.int64)
-        rows.append(np.diff(w[:, :13], axis=1))
+        rows.append(np.diff(w[:, :NS], axis=1))
     cur_pop = env.get_state("n_popped").astype(np.int64)
     if k % (W + K) >= W:
         pops_rows.append((cur_pop - prev_pop).reshape(-1, 64).max(axis=1))      # data packets of the wave's busiest lane
@@ -48,7 +54,7 @@ per_launch_max = np.array([r.sum(axis=1).max() for r in rows])
 print("  slowest wave of a launch: mean %.0f  (the launch lasts at least this long)" % per_launch_max.mean())
 # window-loop cycles against the packet count of the wave's busiest lane: slope = cycles per packet iteration
 mp = np.concatenate(pops_rows)
-loop = d[:, 6]
+loop = d[:, 4 if EXPLICIT else 6]
 A = np.stack([mp, np.ones_like(mp)], axis=1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(A, loop.astype(np.float64), rcond=None)
 print("  window loop ~= %.0f + %.0f x (packets of the busiest lane); busiest lane: median %d, p90 %d, max %d packets" % (coef[1], coef[0], np.median(mp), np.percentile(mp, 90), mp.max()))

@@ -40,7 +40,13 @@ __device__ __forceinline__ GwRec store_q(const GwRunQ& q) { return gw_runq_pack(
 // overlaps everything else); DT == 0: any sender count, loaded where needed.
 // DYN: the live physical layer (f64 received power per radio in st.rxp, BER on the device, link powers shared or per env)
 // instead of the noise-state bytes -- for layouts without a finite noise-state set; instantiated for DT == 0 only.
-template <int DT, bool PER_ENV_STATS, bool DYN>
+// SPLIT (DT > 0, table PHY): blocks of TWO waves over the same 64 envs.  Wave 0 walks the addressed sender's window (the
+// step's critical path); wave 1, the helper, gives every OTHER sender's queue the step's counter ticks -- their number
+// follows from the announcement's timing alone (all ticks up to t_end), not from the walk.  A lone wave per SIMD issues one
+// instruction every ~8 cycles whatever it is (in-kernel stamps: the other senders' queues were 3 700 of a wave's 19 600
+// cycles at D = 4), so taking instructions OFF the walker's stream is what shortens the launch; the helper's wave runs
+// beside it on another SIMD of the CU.  The two waves write disjoint records (queue d / queues != d).
+template <int DT, bool PER_ENV_STATS, bool DYN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                                                         const int32_t* __restrict__ device,
                                                         const int32_t* __restrict__ duration,
@@ -48,8 +54,10 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                                                         float* __restrict__ reward,
                                                         uint8_t* __restrict__ done)
 {
+    static_assert(!SPLIT || (DT > 0 && !DYN), "the split form exists for compile-time sender counts on the table PHY");
     const int64_t N = st.N;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = SPLIT ? (int64_t)blockIdx.x * 64 + (threadIdx.x & 63) : (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool helper = SPLIT && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 1;      // wave-uniform
     // the handle's constants BY VALUE through the constant address space (scalar loads the compiler may hoist and keep;
     // through the plain reference every use was a fresh global load); run-time indexed members go through the pointer
     const GwDevConst* cp = st.cst;
@@ -131,6 +139,57 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
         return st.xs[(size_t)e * st.XB + j];
     };
 
+    if (SPLIT && helper) {
+        Tally kh = {0, 0, 0, 0, 0};
+        if (e < N && (unsigned)d < (unsigned)D && (unsigned)du < (unsigned)c.max_duration) {
+            const StepMath m(c);
+            const double interval = c.counter_interval;
+            const uint32_t bound = (uint32_t)c.counter_bound;
+            const uint32_t base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
+            const int slots = du * c.duration_factor;                     // counter_traffic.py:149
+            const int La = ndigits(slots) + (c.float_duration ? 2 : 0);
+            const TxTimes an = tx_times(m, xw0.x, c.hdr_dur, m.over_rate((double)(La * 8)));
+            const double t_end = an.t_e + (double)(slots + 1) * c.slot;   // simple_stack.py:557-558
+            // every counter tick up to and including t_end (the walker counts the same running-sum sequence piecewise)
+            double wake = xw0.y, delta = 0.0;
+            uint32_t n_ticks = 0;
+            {
+                uint32_t nj = 0;
+                double wj = wake;
+                bool tiej = false, sane = false;
+                const bool span_ok = c.fast_ticks && gw_tick_span_ok(wake, t_end, interval, &delta);
+                gw_tick_jump_lo(wake, t_end, delta, c.inv_interval_lo, true, &nj, &wj, &tiej, &sane);
+                if (span_ok && sane) {
+                    n_ticks = nj;
+                } else {
+                    for (;;) {
+                        const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
+                        const bool b0 = wake <= t_end, b1 = w1 <= t_end, b2 = w2 <= t_end, b3 = w3 <= t_end;
+                        n_ticks += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;   // monotone
+                        wake = w4;
+                        if (!b3) break;
+                    }
+                }
+            }
+            const uint32_t ctr0 = xc0.x;
+#pragma unroll
+            for (int i = 0; i < DR; ++i) {
+                const uint32_t mult_i = (uint32_t)c.mult[i];
+                if (i != d && n_ticks != 0u && mult_i != 0u) {
+                    GwRunQ ri = load_q(qr[i]);
+                    gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, c.inv20[i], kh);
+                    st.qrec[(int64_t)i * N + e] = store_q(ri);
+                }
+            }
+            if (PER_ENV_STATS) {
+                if (kh.app) atomicAdd(&st.pe_stats[2 * N + e], (unsigned long long)kh.app);
+                if (kh.drop) atomicAdd(&st.pe_stats[4 * N + e], (unsigned long long)kh.drop);
+            }
+        }
+        publish_totals(st.totals, kh, 0u, 0u, 0u);
+        return;
+    }
+
     // What the step leaves behind is held in registers and STORED AT THE VERY END, behind the wave's totals: the tail of the
     // kernel reuses registers, and a register that is the data of a store in flight is not free before that store has
     // completed (the compiler waits on vmcnt) -- with the stores first, the totals sat out a full store round trip.
@@ -144,6 +203,8 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
     uint4 out_xs[NXW];
     uint32_t out_xs_dirty = 0u;
     Tally out_pe = {0, 0, 0, 0, 0};
+    GwRec out_rec_d = {0u, 0u, 0u, 0u};
+    const int out_d = d;
 
     if (e < N) {
         uint32_t fl = xc0.w;
@@ -323,6 +384,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                             n_ticks++;
                         } else break;
                     }
+                    STAMP(12);
                     const uint32_t s = rd.H.v0;                           // the head run's first packet
                     const double need = m.over_rate((double)(s * 8u));    // messages.py:67-75
                     if (!((stopw - cur) > need)) break;                   // :418-420 idle until the window ends
@@ -332,6 +394,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
                     k.tx++;
                     n_data++;
+                    STAMP(13);
                     double ber_x = ber_x1;
                     uint32_t cls_x = cls_x1;
                     if (DYN) {
@@ -371,8 +434,10 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                         if (receive(m, ber_p, x, br, hdr_bits, (double)(pay * 8) * c.coded_factor, fl)) n_peer++;
                     }
                     if (!(x.t_e < t_end)) fl |= GW_FLAG_CARRY;
+                    STAMP(14);
                     // ticks are older events than the MAC's resume at t_e: they go first
                     ticks_upto(x.t_e, true);
+                    STAMP(15);
                     cur = x.t_e;
                     if (!(cur < stopw)) break;                            // window timeout already processed
                 }
@@ -390,7 +455,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 for (int i = 0; i < DR; ++i) {
                     GwRec ro = qr[i];
                     const uint32_t mult_i = (uint32_t)c.mult[i];
-                    if (i != d && n_ticks != 0u && mult_i != 0u) {
+                    if (!SPLIT && i != d && n_ticks != 0u && mult_i != 0u) {
                         GwRunQ ri = load_q(qr[i]);
                         gw_runq_ticks(ri, n_ticks, ctr0, bound, base_bytes, st.runs + (((int64_t)e * D + i) << 7), mult_i, c.inv20[i], k);
                         ro = store_q(ri);
@@ -503,6 +568,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             out_xw = make_double2(t_end, wake);
             out_xc = make_uint4(ctr_new, rvm, (uint32_t)last_abs | ((uint32_t)dn << 31), fl);
             out_pe = k;
+            out_rec_d = rec_d;
         }
         fl_new = fl;
     }
@@ -521,17 +587,26 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
 #pragma unroll
             for (int w = 0; w < NXW; ++w)
                 if ((out_xs_dirty >> w) & 1u) reinterpret_cast<uint4*>(st.xs + (size_t)e * st.XB)[w] = out_xs[w];
+            if (SPLIT) {                                   // the addressed sender's record only: the others are the helper's
+                st.qrec[(int64_t)out_d * N + e] = out_rec_d;
+            } else {
 #pragma unroll
-            for (int i = 0; i < DR; ++i) st.qrec[(int64_t)i * N + e] = qout[i];
+                for (int i = 0; i < DR; ++i) st.qrec[(int64_t)i * N + e] = qout[i];
+            }
         }
         reinterpret_cast<double2*>(st.xw)[e] = out_xw;
         reinterpret_cast<uint4*>(st.xc)[e] = out_xc;
         if (PER_ENV_STATS) {
             st.pe_stats[0 * N + e] += out_pe.tx;
             st.pe_stats[1 * N + e] += out_pe.deliv;
-            st.pe_stats[2 * N + e] += out_pe.app;
             st.pe_stats[3 * N + e] += out_pe.pop;
-            st.pe_stats[4 * N + e] += out_pe.drop;
+            if (SPLIT) {                                   // (the helper adds the other senders' share to these two)
+                if (out_pe.app) atomicAdd(&st.pe_stats[2 * N + e], (unsigned long long)out_pe.app);
+                if (out_pe.drop) atomicAdd(&st.pe_stats[4 * N + e], (unsigned long long)out_pe.drop);
+            } else {
+                st.pe_stats[2 * N + e] += out_pe.app;
+                st.pe_stats[4 * N + e] += out_pe.drop;
+            }
         }
     }
     STAMP(11);
@@ -627,8 +702,20 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
 {
     const unsigned blk = (unsigned)st.block;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
+    static const bool no_split = getenv("GW_NO_SPLIT") != nullptr;                      // A/B switch
+    const bool split = blk == 64u && !no_split;
+#define GW_LAUNCH_SPLIT(DT_)                                                                                     \
+    do {                                                                                                        \
+        if (st.pe_stats)                                                                                        \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, true, false, true>), dim3(grid), dim3(128), 0, (hipStream_t)stream, \
+                               st, device, duration, obs, reward, done);                                        \
+        else                                                                                                    \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, false, false, true>), dim3(grid), dim3(128), 0, (hipStream_t)stream, \
+                               st, device, duration, obs, reward, done);                                        \
+    } while (0)
 #define GW_LAUNCH_GENERIC(DT_)                                                                                   \
     do {                                                                                                        \
+        if (split && (DT_) > 0) { constexpr int dts_ = ((DT_) > 0) ? (DT_) : 2; GW_LAUNCH_SPLIT(dts_); break; }      \
         if (st.pe_stats)                                                                                        \
             hipLaunchKernelGGL((ct_step_kernel<DT_, true, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, \
                                st, device, duration, obs, reward, done);                                        \
@@ -652,6 +739,7 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
     default: GW_LAUNCH_GENERIC(0); break;
     }
 #undef GW_LAUNCH_GENERIC
+#undef GW_LAUNCH_SPLIT
     return check_launch();
 }
 

@@ -461,7 +461,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     }
     if (explicit_q && (cfg->flags & GW_CFG_PEER_RECEIVE)) TRY_ALLOC(st.peer_rx, N * D);
     if (explicit_q && (cfg->flags & GW_CFG_PER_ENV_STATS)) TRY_ALLOC(st.pe_stats, N * 5);
-    st.n_slots = (N + 15) / 16;                       // one per wave; sized for the narrowest block (16)
+    st.n_slots = (N + 15) / 16 + 1;                   // one per wave; sized for the narrowest block (16) and for two waves per 64 envs
     if (explicit_q) TRY_ALLOC(st.totals, st.n_slots * GW_T_COUNT);
 #ifdef GW_STAMPS
     TRY_ALLOC(st.stamps, st.n_slots * 16);

@@ -26,6 +26,7 @@ if EXPLICIT:
              "4 window loop", "5 tail ticks", "6 other senders' queues", "7 noise states", "8 feedback values", "9 totals", "10 all stores"]
 NS = len(names) + 1
 rows = []
+rows_loop = []
 pops_rows = []
 prev_pop = env.get_state("n_popped").astype(np.int64)
 for k in range(3 * (W + K)):
@@ -35,11 +36,12 @@ for k in range(3 * (W + K)):
     env.step(a)
     torch.cuda.synchronize()
     if k % (W + K) >= W:
-        n_slots = (N + 15) // 16
+        n_slots = (N + 15) // 16 + 1
         out = np.empty((n_slots, 16), np.uint64)
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         w = out[: N // 64].astype(np.int64)
         rows.append(np.diff(w[:, :NS], axis=1))
+        rows_loop.append(w[:, 12:16].copy())
     cur_pop = env.get_state("n_popped").astype(np.int64)
     if k % (W + K) >= W:
         pops_rows.append((cur_pop - prev_pop).reshape(-1, 64).max(axis=1))      # data packets of the wave's busiest lane
@@ -48,6 +50,15 @@ d = np.concatenate(rows)
 print("cycles per wave (s_memtime ticks; each stamp itself costs ~100), median / p90 / mean / max over %d waves x %d launches (steps %d..%d after a reset)" % (N // 64, len(rows), W, W + K - 1))
 for i, n in enumerate(names):
     print("  %-48s %8.0f %8.0f %8.0f %8.0f" % (n, np.median(d[:, i]), np.percentile(d[:, i], 90), d[:, i].mean(), d[:, i].max()))
+if EXPLICIT:
+    # phases of the window loop's LAST iteration (stamps 12..15 are overwritten by every iteration)
+    ph = np.concatenate(rows_loop)
+    # (lane 0 of the wave takes the stamps; its last visit to the loop top usually ends at the fit test, so 12 is newer than 13)
+    for i, n in enumerate(["12->13 head size, fit test, pop, tx_times", "13->14 decode (+ peer)", "14->15 ticks up to t_e"]):
+        sel = (ph[:, i + 1] > ph[:, i]) & (ph[:, i] > 0)
+        x = (ph[sel, i + 1] - ph[sel, i])
+        if x.size:
+            print("  loop phase %-44s median %6.0f mean %6.0f  (%d samples)" % (n, np.median(x), x.mean(), x.size))
 tot = d.sum(axis=1)
 print("  %-48s %8.0f %8.0f %8.0f %8.0f" % ("total in-kernel", np.median(tot), np.percentile(tot, 90), tot.mean(), tot.max()))
 per_launch_max = np.array([r.sum(axis=1).max() for r in rows])

@@ -20,7 +20,7 @@ for k in range(48):
     penv.step(a)
     torch.cuda.synchronize()
     if k >= 8:
-        n_slots = (N + 15) // 16
+        n_slots = (N + 15) // 16 + 1
         out = np.empty((n_slots, 16), np.uint64)
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         rows.append(np.diff(out[: N // 64].astype(np.int64), axis=1))

@@ -374,6 +374,58 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                 double cur = t_r;
                 // ties at the window start: the MAC's process initialisation is URGENT, so it runs first
                 ticks_upto(cur, false);
+                // ---- the window loop, straight-line form (the default kernel's, ct_step_sfx.hip: a lone wave per SIMD issues
+                //      an instruction every ~8 cycles whatever it is, so the per-packet decisions are settled for the whole
+                //      step up front where they can be).  A lane takes it when tick jumps apply (span_ok), the exact fast
+                //      forms of fmod and division hold up to t_end, the RRM's decode outcome is certain by class and its noise
+                //      state idempotent, no receive-mode peer listens, and t_r >= 2 (t_end - t_r): then every packet's
+                //      stop - t_s is exact (Sterbenz) and the completion event t_s + (stop - t_s) IS stop.  One exit
+                //      condition, no branch inside but the run-queue's own (rarely taken) general paths; it ends when the
+                //      window closes, the next packet does not fit, or the queue runs empty (the general loop below then
+                //      waits for the tick).  GW_FLAG_CARRY can only be raised by a window's last packet: tested once.
+                bool more = true;
+                uint32_t pops = 0;
+                {
+                    const double span = t_end - t_r;
+                    const bool straight = !DYN && span_ok && mult_d != 0u && idem && cls_valid && cls_x1 != (uint32_t)GW_CLS_COMPUTE &&
+                                          m.fast_fmod && m.fast_div && t_end < m.fmod_limit && t_r >= span + span && j_peer < 0;
+                    if (straight && rd.len != 0u) {
+                        uint32_t chk = 0;
+                        uint32_t s = rd.H.v0;
+                        bool go = (stopw - cur) > gw_fast_div((double)(s * 8u), m.dr, m.rcp_dr);       // :418-420
+                        while (go) {
+                            const double pd = gw_fast_div((double)(((int)s - mh) * 8), m.dr, m.rcp_dr);
+                            const double t_s = cur + (m.slot - gw_fast_fmod_lo(cur, m.slot, c.inv_slot_lo));
+                            const double t_e = t_s + (hd + pd);
+                            uint32_t nj = 0;
+                            double wj = wake;
+                            bool tiej = false, sane = false;
+                            gw_tick_jump_lo(wake, t_e, delta, c.inv_interval_lo, true, &nj, &wj, &tiej, &sane);
+                            chk |= (sane ? 0u : (uint32_t)GW_FLAG_INTERNAL) | (tiej ? (uint32_t)GW_FLAG_TIE : 0u);
+                            // the pop (:425) and the ticks inside the transmission, in one queue operation (gw_runq.h)
+                            gw_runq_pop1_ticks(rd, nj, ctr0 + n_ticks, bound, base_bytes, ring_d, mult_d, inv20_d, k);
+                            n_ticks += nj;
+                            wake = wj;
+                            cur = t_e;
+                            pops++;
+                            s = rd.H.v0;
+                            go = cur < stopw && rd.len != 0u && (stopw - cur) > gw_fast_div((double)(s * 8u), m.dr, m.rcp_dr);
+                        }
+                        more = cur < stopw && rd.len == 0u;               // an empty queue waits for a tick: general loop
+                        fl |= chk | ((pops && !(cur < t_end)) ? (uint32_t)GW_FLAG_CARRY : 0u);
+                    }
+                }
+                if (pops) {                                               // devices.py:163-168, counter_traffic.py:75-80
+                    const bool okx = cls_x1 == (uint32_t)GW_CLS_OK;
+                    k.pop += pops;
+                    k.tx += pops;
+                    n_data += (int)pops;
+                    s_r = s_r1;
+                    k.deliv += okx ? pops : 0u;
+                    rvm |= okx ? (1u << d) : 0u;
+                    dn = (okx && pv == c.counter_bound) ? (uint8_t)1 : dn;
+                }
+                if (more)
                 for (;;) {
                     if (rd.len == 0u) {                                   // :409-416
                         // (a silent sender, mult 0, never signals packet-added: the MAC waits for the timeout)

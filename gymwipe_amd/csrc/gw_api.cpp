@@ -1031,12 +1031,30 @@ int gw_selftest_runq(uint64_t seed, int32_t operations, int32_t mult, int32_t co
             if (ref.size() == GW_QUEUE_CAP) { ref.pop_front(); gw_runq_pop_front(q, 1u, ring.data(), m, inv20, cap); }
             ref.push_back(size);
             gw_runq_append_literal(q, size, ring.data());
-        } else {                                          // window pops
-            uint32_t n = 1 + rnd(what == 15 ? 60 : 4);
+        } else if (what < 14) {                           // window pops
+            uint32_t n = 1 + rnd(what == 13 ? 60 : 4);
             while (n-- && !ref.empty()) {
                 if (q.len != ref.size() || q.state == 0u || q.H.v0 != ref.front()) ++bad;
                 ref.pop_front();
                 gw_runq_pop_front(q, 1u, ring.data(), m, inv20, cap);
+            }
+        } else {                                          // a window: pop one packet + the ticks inside its transmission, fused
+            uint32_t n = 1 + rnd(9);
+            while (n-- && !ref.empty()) {
+                if (q.len != ref.size() || q.state == 0u || q.H.v0 != ref.front()) ++bad;
+                ref.pop_front();
+                const uint32_t k = rnd(5);                // 0..4 ticks
+                uint32_t c = ctr;
+                for (uint32_t t = 0; t < k; ++t) {
+                    for (uint32_t j = 0; j < m; ++j) {
+                        if (ref.size() == GW_QUEUE_CAP) { ref.pop_front(); ++ref_drops; }
+                        ref.push_back(base + c);
+                        ++ref_apps;
+                    }
+                    if (c < bound) ++c;
+                }
+                gw_runq_pop1_ticks(q, k, ctr, bound, base, ring.data(), m, inv20, tally);
+                ctr = c;
             }
         }
         q = gw_runq_unpack(gw_runq_pack(q));              // through the 16-byte record, as between two steps

@@ -217,6 +217,14 @@ GW_HD void gw_runq_ticks(GwRunQ& q, uint32_t k, uint32_t c, uint32_t bound, uint
     const uint32_t qq = (e * inv20) >> 20;
     const uint32_t nv = lv0 + qq;
     const bool cont = !none && !llit && e - qq * mult == 0u && (nv < cap ? nv : cap) == v;   // the tick continues the last run
+    if (one && cont) {
+        // the steady state of counter traffic: ONE run, and the ticks extend it -- lengthen it, advance its head past the drops
+        // (drops < n + add: the queue keeps CAP packets)
+        q.H.n += add;
+        q.len = want - drops;
+        gw_run_advance_sel(q.H, drops, mult, inv20, cap);
+        return;
+    }
     if (q.M == 0u && (cont || q.state != 2u)) {
         const bool to_h = none || (one && cont), to_t = !none && !(one && cont);            // which slot the packets go to
         const bool fresh = !cont;                                                            // ... as a new run
@@ -231,6 +239,33 @@ GW_HD void gw_runq_ticks(GwRunQ& q, uint32_t k, uint32_t c, uint32_t bound, uint
     }
     gw_runq_append_counter(q, add, v, ring, mult, inv20, cap);
     if (drops) gw_runq_pop_front(q, drops, ring, mult, inv20, cap);
+}
+
+// the window loop's pair of operations on the addressed sender's queue, back to back: pop the head packet (simple_stack.py:425),
+// then the k counter ticks that fall into its transmission (k may be 0).  In the steady state -- one counter run of at least two
+// packets which the ticks continue -- the two are ONE advance of the run's head by 1 + drops.
+GW_HD void gw_runq_pop1_ticks(GwRunQ& q, uint32_t k, uint32_t c, uint32_t bound, uint32_t base_bytes, uint64_t* ring,
+                              uint32_t mult, uint32_t inv20, GwTally& t)
+{
+    const uint32_t cap = base_bytes + bound;
+    const uint32_t add = k * mult;
+    const uint32_t e = q.H.j + q.H.n;                    // (invariant under advancing the head)
+    const uint32_t qq = (e * inv20) >> 20;
+    const uint32_t nv = q.H.v0 + qq;
+    const uint32_t v = base_bytes + (c < bound ? c : bound);
+    const bool cont = e - qq * mult == 0u && (nv < cap ? nv : cap) == v;
+    if (q.state == 1u && q.H.lit == 0u && q.H.n >= 2u && k <= (uint32_t)GW_QUEUE_CAP && mult != 0u && (add == 0u || cont)) {
+        const uint32_t want = q.len - 1u + add;
+        const uint32_t drops = want > (uint32_t)GW_QUEUE_CAP ? want - (uint32_t)GW_QUEUE_CAP : 0u;
+        t.app += add;
+        t.drop += drops;
+        q.H.n += add;
+        q.len = want - drops;
+        gw_run_advance_sel(q.H, 1u + drops, mult, inv20, cap);
+        return;
+    }
+    gw_runq_pop_front(q, 1u, ring, mult, inv20, cap);
+    gw_runq_ticks(q, k, c, bound, base_bytes, ring, mult, inv20, t);
 }
 
 // host: the queue's packets, head first (out has room for GW_QUEUE_CAP); returns the length

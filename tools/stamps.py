@@ -40,6 +40,8 @@ for k in range(3 * (W + K)):
         out = np.empty((n_slots, 16), np.uint64)
         nat.check(env._L.gw_get_state(env._h, b"stamps", out.ctypes.data, out.nbytes))
         w = out[: N // 64].astype(np.int64)
+        if EXPLICIT and not os.environ.get("GW_NO_SPLIT"):      # two waves per 64 envs: even = the walker, odd = the helper
+            w = out[: 2 * (N // 64)].astype(np.int64)[0::2]
         rows.append(np.diff(w[:, :NS], axis=1))
         rows_loop.append(w[:, 12:16].copy())
     cur_pop = env.get_state("n_popped").astype(np.int64)

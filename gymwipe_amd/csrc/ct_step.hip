@@ -139,9 +139,25 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
         return st.xs[(size_t)e * st.XB + j];
     };
 
+    // SPLIT: the helper also writes the radios' noise-state record (every radio heard the announcement and, if any, d's
+    // data): the lookups are its own, what it needs from the walk -- whether data was sent, d's and the RRM's new states --
+    // comes through LDS behind a workgroup barrier that BOTH waves pass exactly once, at their converged ends.  Table PHY with
+    // idempotent states and no receive-mode peers only (both wave-uniform); otherwise the walker keeps the record.
+    __shared__ uint32_t s_info[SPLIT ? 64 : 1];
+    const bool xs_by_helper = SPLIT && c.idem_states != 0 && !c.peer_receive;
     if (SPLIT && helper) {
         Tally kh = {0, 0, 0, 0, 0};
-        if (e < N && (unsigned)d < (unsigned)D && (unsigned)du < (unsigned)c.max_duration) {
+        const bool valid_h = e < N && (unsigned)d < (unsigned)D && (unsigned)du < (unsigned)c.max_duration;
+        uint8_t n1h[DR], n2h[DR];
+        if (xs_by_helper && valid_h) {
+#pragma unroll
+            for (int j = 0; j < DR; ++j) {
+                const uint8_t s0 = xs_get(j);
+                n1h[j] = s_h1[j * S + s0];
+                n2h[j] = g_h2[(j * D + d) * S + s0];
+            }
+        }
+        if (valid_h) {
             const StepMath m(c);
             const double interval = c.counter_interval;
             const uint32_t bound = (uint32_t)c.counter_bound;
@@ -187,6 +203,34 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             }
         }
         publish_totals(st.totals, kh, 0u, 0u, 0u);
+        __syncthreads();                                   // the walker's word is in LDS
+        if (xs_by_helper && valid_h) {
+            const uint32_t info = s_info[threadIdx.x & 63];
+            if (info & 1u) {                               // a good step: {1, data sent, d's state, the RRM's state}
+                const bool data = (info >> 1) & 1u;
+                uint32_t nbx[16 * NXW];
+#pragma unroll
+                for (int b = 0; b < 16 * NXW; ++b) {
+                    const uint4& w = xsw[b >> 4];
+                    const uint32_t word = ((b >> 2) & 3) == 0 ? w.x : (((b >> 2) & 3) == 1 ? w.y : (((b >> 2) & 3) == 2 ? w.z : w.w));
+                    nbx[b] = (word >> ((b & 3) * 8)) & 0xffu;
+                }
+#pragma unroll
+                for (int j = 0; j < DT; ++j) nbx[j] = j == d ? ((info >> 8) & 0xffu) : (data ? (uint32_t)n2h[j] : (uint32_t)n1h[j]);
+                nbx[DT] = (info >> 16) & 0xffu;
+#pragma unroll
+                for (int w = 0; w < NXW; ++w) {
+                    const int b = 16 * w;
+                    uint4 o;
+                    o.x = nbx[b + 0] | (nbx[b + 1] << 8) | (nbx[b + 2] << 16) | (nbx[b + 3] << 24);
+                    o.y = nbx[b + 4] | (nbx[b + 5] << 8) | (nbx[b + 6] << 16) | (nbx[b + 7] << 24);
+                    o.z = nbx[b + 8] | (nbx[b + 9] << 8) | (nbx[b + 10] << 16) | (nbx[b + 11] << 24);
+                    o.w = nbx[b + 12] | (nbx[b + 13] << 8) | (nbx[b + 14] << 16) | (nbx[b + 15] << 24);
+                    if (o.x != xsw[w].x || o.y != xsw[w].y || o.z != xsw[w].z || o.w != xsw[w].w)
+                        reinterpret_cast<uint4*>(st.xs + (size_t)e * st.XB)[w] = o;
+                }
+            }
+        }
         return;
     }
 
@@ -205,6 +249,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
     Tally out_pe = {0, 0, 0, 0, 0};
     GwRec out_rec_d = {0u, 0u, 0u, 0u};
     const int out_d = d;
+    uint32_t out_info = 0u;
 
     if (e < N) {
         uint32_t fl = xc0.w;
@@ -298,7 +343,7 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             // (n2): looked up NOW, consumed after the window -- a load issued behind the step's first stores would wait for
             // those stores to complete (vmcnt counts loads and stores in one order), a microsecond apiece
             uint8_t n1[DR], n2[DR];
-            if (DT > 0 && !DYN) {
+            if (DT > 0 && !DYN && !xs_by_helper) {
 #pragma unroll
                 for (int j = 0; j < DR; ++j) {
                     const uint8_t s0 = xs_get(j);
@@ -573,7 +618,9 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
                     for (int n = 0; n < n_data; ++n) sj = st.trans[((int64_t)j * R + d) * S + sj];
                     return sj;
                 };
-                if (DT > 0) {
+                if (xs_by_helper) {
+                    out_info = 1u | (n_data ? 2u : 0u) | ((uint32_t)s_d << 8) | ((uint32_t)s_r << 16);
+                } else if (DT > 0) {
                     uint32_t nbx[16 * NXW];
 #pragma unroll
                     for (int b = 0; b < 16 * NXW; ++b) {
@@ -623,6 +670,10 @@ __global__ __launch_bounds__(256) void ct_step_kernel(GwState st,
             out_rec_d = rec_d;
         }
         fl_new = fl;
+    }
+    if (SPLIT) {                                           // (converged: every lane of both waves gets here exactly once)
+        s_info[threadIdx.x & 63] = out_info;
+        __syncthreads();
     }
     STAMP(9);
     publish_totals(st.totals, k, k_steps, k_bad, fl_new);

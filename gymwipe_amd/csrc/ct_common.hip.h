@@ -263,19 +263,24 @@ __device__ __forceinline__ void publish_totals(unsigned long long* totals, const
     // every event count gets a full 32-bit word (a lane can pop hundreds of packets per step at a high bit rate);
     // steps, bad <= 64 each share one
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t w_tx = gw_wave_total<false>(k.tx), w_deliv = gw_wave_total<false>(k.deliv), w_pop = gw_wave_total<false>(k.pop);
+    const uint32_t w_deliv = gw_wave_total<false>(k.deliv), w_pop = gw_wave_total<false>(k.pop);
     const uint32_t w_app = gw_wave_total<false>(k.app), w_drop = gw_wave_total<false>(k.drop);
-    const uint32_t w_sb = gw_wave_total<false>(k_steps | (k_bad << 8));
-    const uint32_t w_fl = gw_wave_total<true>(fl_new);
+    // steps and bad actions are 0 or 1 per lane: population counts of two lane masks; transmissions are a step's announcement
+    // plus its data packets, lane by lane; the sticky flags are rarely set: their reduction runs only if some lane has one
+    const uint32_t w_steps = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(k_steps != 0u));
+    const uint32_t w_bad = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(k_bad != 0u));
+    const uint32_t w_tx = w_steps + w_pop;
+    uint32_t w_fl = 0u;
+    if (__builtin_amdgcn_ballot_w64(fl_new != 0u)) w_fl = gw_wave_total<true>(fl_new);
     if (lane < (uint32_t)GW_T_COUNT) {
-        uint32_t w = w_sb & 0xffu;                                   // GW_T_STEPS
+        uint32_t w = w_steps;                                         // GW_T_STEPS
         w = lane == (uint32_t)GW_T_TX ? w_tx : w;
         w = lane == (uint32_t)GW_T_DELIV ? w_deliv : w;
         w = lane == (uint32_t)GW_T_APP ? w_app : w;
         w = lane == (uint32_t)GW_T_POP ? w_pop : w;
         w = lane == (uint32_t)GW_T_DROP ? w_drop : w;
         w = lane == (uint32_t)GW_T_FLAGS ? w_fl : w;
-        w = lane == (uint32_t)GW_T_BAD ? (w_sb >> 8) : w;
+        w = lane == (uint32_t)GW_T_BAD ? w_bad : w;
         const size_t waves_per_block = (blockDim.x + 63) >> 6;
         const size_t wave = (size_t)blockIdx.x * waves_per_block + (threadIdx.x >> 6);
         unsigned long long* t = totals + wave * GW_T_COUNT;

@@ -208,6 +208,15 @@ __device__ __forceinline__ GwDevConst hdr_const(const uint32_t* ip, int n_dev)
     const uint8_t* at = reinterpret_cast<const uint8_t*>(ip) - gw_blob_header(D) + gw_hdr_cst_off(D);
     return *(const GW_AS_CONST GwDevConst*)at;                                   // (only the fields the body uses are loaded)
 }
+// A pointer READ FROM MEMORY is a generic pointer to the compiler: every access through it becomes a FLAT instruction (both
+// the LDS and the vector-memory counters, no scalar base + 32-bit offset addressing; the live-PHY kernel's row loads were all
+// flat: in-kernel stamps put 48 of them at ~300 cycles apiece).  Through a cast to the global address space and back, address-
+// space inference turns the accesses into global ones.  (Kernel ARGUMENTS are known to be global without this.)
+template <class T>
+__device__ __forceinline__ T* gw_as_global(T* p)
+{
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
 template <int DT>
 __device__ __forceinline__ GwState hdr_state(uint32_t* ip, double* tw, uint32_t* tk, uint8_t* qb, uint32_t n_envs, int n_dev)
 {
@@ -216,6 +225,10 @@ __device__ __forceinline__ GwState hdr_state(uint32_t* ip, double* tw, uint32_t*
     GwState st = *(const GW_AS_CONST GwState*)(base + gw_hdr_st_off(D));
     st.ip = ip; st.tw = tw; st.tk = tk; st.qb = qb; st.N = (int64_t)n_envs; st.D = D;
     st.blob = base;
+#define GW_G(m) st.m = gw_as_global(st.m)
+    GW_G(bph); GW_G(sa); GW_G(trans); GW_G(ber); GW_G(cls); GW_G(ber2); GW_G(cls2); GW_G(rxp); GW_G(prx_tab); GW_G(pos_tab);
+    GW_G(extra_tab); GW_G(prx_env); GW_G(pos_env); GW_G(bcache); GW_G(talk); GW_G(stamps); GW_G(cst);
+#undef GW_G
     return st;
 }
 
@@ -226,14 +239,13 @@ __device__ __forceinline__ int ndigits(int v)             // messages.py:51-52 l
 }
 
 
-// Event totals.  Each wave owns one 64-byte slot (GW_T_COUNT u64 words) in HBM; gw_stats_read sums
-// the slots on the host.  What was measured on MI355X on the way here:
+// Event totals of the generic kernel.  Each wave owns one 64-byte slot (GW_T_COUNT u64 words) in HBM; gw_stats_read sums the
+// slots on the host.  What was measured on MI355X on the way here:
 //   * eight global atomics per wave on ONE shared line serialised the whole launch (~90 us);
 //   * eight 64-lane shuffle reductions + load/add/store of the private slot: 43% of a wave's cycles;
-//   * three packed shuffle reductions + atomics on the private line: still ~2.1k cycles per wave.
-// Now: the per-lane counters go into seven words summed by LDS atomics (one ds_add per word for the whole
-// wave), and lanes 0..7 issue ONE global atomic instruction on the wave's line.  Appends and drops get a full
-// 32-bit word each (64 lanes x 21 ticks x multiplicity 100 = 134 400 per wave does not fit 16 bits).
+//   * seven words summed by LDS atomics (one ds_add per word, all 64 lanes on one address): the lanes serialise, 2 700 cycles;
+//   * now: four DPP reductions (delivered, popped, appended, dropped), two population counts (steps, bad actions), the flags
+//     only when a lane has one, and ONE no-return global atomic instruction by lanes 0..7 on the wave's own line.
 // sum / OR over the wave's 64 lanes on the DPP path (result in lane 63): an inclusive scan within each row of 16 lanes
 // (row_shr 1, 2, 4, 8; lanes shifted in from outside the row contribute 0), then the row totals carried across rows
 // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six VALU instructions per word -- the LDS atomics this

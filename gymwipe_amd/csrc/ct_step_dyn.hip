@@ -34,10 +34,16 @@ using namespace gwk;
 
 namespace {
 
+// (through the GLOBAL address space: the pointers of this kernel's state come from the header in memory, and an access through
+//  a pointer read from memory is a FLAT instruction unless told otherwise -- ct_common.hip.h, hdr_state)
 template <class T>
 __device__ __forceinline__ T ld(const void* base, size_t byte_off)
 {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(1))) T*)(reinterpret_cast<const char*>(base) + byte_off);
+#else
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);       // (host pass: never executed)
+#endif
 }
 template <class T>
 __device__ __forceinline__ void st_(void* base, size_t byte_off, const T& v)
@@ -117,6 +123,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
     const size_t orx = (size_t)el * RP * 8u;                     // the env's row of received powers
     const size_t olk = (size_t)el * R * RP * 8u;                 // the env's link matrix (PER_ENV)
 
+    STAMP(0);
     // shared geometry: the handle's [R][R] link table -> LDS once per workgroup
     __shared__ double s_prx[PER_ENV ? 1 : (GW_MAX_RADIOS * GW_MAX_RADIOS)];
     if (!PER_ENV) {
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
     asm volatile("" : "+v"(d), "+v"(du));
     asm volatile("" : "+v"(bp.x), "+v"(bp.y), "+v"(bp.z), "+v"(bp.w));
     __syncthreads();                                             // s_prx, s_mi
+    STAMP(1);
 
     const bool bad = (unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration;
     const int dq = bad ? 0 : d;                                   // a valid index for the dependent loads below
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         for (int h = 0; h < NH; ++h) pdv[h] = ld<double2>(st.prx_env, olk + ((size_t)dq * RP) * 8u + 16u * h);
     }
     auto link = [&](int from, int to) -> double {
-        return PER_ENV ? st.prx_env[((size_t)el * R + from) * RP + to] : s_prx[from * R + to];
+        return PER_ENV ? ld<double>(st.prx_env, (((size_t)el * R + from) * RP + to) * 8u) : s_prx[from * R + to];
     };
     double rx_d0, rx_r0, p_a, p_x;
     if (ROWS) {
@@ -187,14 +195,48 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             p_a = link(RRM, dq);
         }
     } else {
-        rx_d0 = st.rxp[(size_t)el * RP + dq];
-        rx_r0 = st.rxp[(size_t)el * RP + RRM];
+        rx_d0 = ld<double>(st.rxp, ((size_t)el * RP + dq) * 8u);
+        rx_r0 = ld<double>(st.rxp, ((size_t)el * RP + RRM) * 8u);
         p_a = link(RRM, dq);
     }
     // the attenuation of a pair is one number (one model per unordered pair, physical.py:500-528; gw_create refuses an
     // asymmetric extra_att_db) and every radio sends with the same power: the link matrix is symmetric bit for bit, so the
     // RRM hears d with the power d hears the RRM with -- no load that waits for the action
     p_x = p_a;
+
+    // ---- all-pairs, D = 8 / 16 / 32, first half: the listeners' loads, NOW.  Groups of D lanes, one lane per listening radio, one
+    // env per group and pass; what a lane reads (its radio's received power and its links to the RRM and to the env's talker)
+    // depends on the env's action only, so every pass's loads are issued here, in front of the walk, and their round trip to
+    // memory (in-kernel stamps at D = 16: ~4 000 cycles each for the four batches the pass used to run in) passes while the
+    // walker walks.  The second half -- the (+p, -p) updates, which need the walk's packet count -- follows the walk.
+    constexpr int CG = COOP ? DT : 1;                             // lanes per env
+    constexpr int CEPP = 64 / CG;                                 // envs per pass
+    constexpr int CNP = COOP ? CG : 1;                            // passes
+    const uint32_t c_lane = threadIdx.x, c_j = c_lane % CG;       // this lane's radio
+    const uint32_t c_act = (live && !bad) ? 1u : 0u;
+    const uint32_t e_wave = blockIdx.x * 64u;                     // first env of the wave (always < N)
+    double c_a0[CNP], c_pa[CNP], c_pd[CNP];
+    uint32_t c_off[CNP];
+    uint64_t c_on = 0ull;                                         // bit u = pass u has a listener for this lane
+    if (COOP) {
+        const uint32_t info0 = (uint32_t)dq | (c_act << 31);
+        const double* rx_wave = st.rxp + (size_t)e_wave * RP;
+        const double* lk_wave = PER_ENV ? st.prx_env + (size_t)e_wave * R * RP : nullptr;
+#pragma unroll
+        for (int u = 0; u < CNP; ++u) {
+            const uint32_t src = (uint32_t)(u * CEPP) + c_lane / CG;          // the lane that walks this group's env
+            const uint32_t w = (uint32_t)__shfl((int)info0, (int)src);
+            const uint32_t dsrc = w & 0xffu;
+            const bool on = (w >> 31) != 0u && c_j != dsrc;
+            c_on |= on ? (1ull << u) : 0ull;
+            const uint32_t es = on ? src : 0u;                    // idle lanes read the wave's first env: a valid row
+            c_off[u] = es * (uint32_t)RP + c_j;
+            c_a0[u] = ld<double>(rx_wave, (size_t)c_off[u] * 8u);
+            c_pa[u] = PER_ENV ? ld<double>(lk_wave, (size_t)((es * (uint32_t)R + (uint32_t)RRM) * (uint32_t)RP + c_j) * 8u) : s_prx[RRM * R + c_j];
+            const uint32_t dr = on ? dsrc : 0u;
+            c_pd[u] = PER_ENV ? ld<double>(lk_wave, (size_t)((es * (uint32_t)R + dr) * (uint32_t)RP + c_j) * 8u) : s_prx[dr * R + c_j];
+        }
+    }
 
     const StepMath m(c);
     uint32_t rvm = tk0.z;                                         // (record layout: ct_step_sfx.hip)
@@ -204,6 +246,16 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
     const int pv = c.payload_value;
     int n_data = 0;                                               // data packets of d this step (0 for a bad action / dead lane)
     double rx_d = rx_d0, rx_r = rx_r0;
+
+    // COOP: what the walk leaves behind is held in registers and stored BEHIND the lane groups' all-pairs pass -- vmcnt counts
+    // loads and stores in one order, so the groups' loads, issued behind the walk's write-through stores, each sat out those
+    // stores' round trip to memory before their own data counted as arrived
+    bool out_commit = false, ca_dirty = false, cx_dirty = false;
+    uint4 out_qb[NWC];
+    int32_t out_obs = 0;
+    float out_rew = 0.0f;
+    double2 out_tw = make_double2(0.0, 0.0);
+    uint4 out_tk = make_uint4(0u, 0u, 0u, 0u);
 
     if (live && bad) {
         // counter_traffic.py:147 asserts; a batched step cannot raise per env: flag + skip
@@ -240,13 +292,13 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         const GwBp* hist = st.bph + ((size_t)e << 7);
         const int slots = du * c.duration_factor;                         // counter_traffic.py:149
 
+        STAMP(2);
         // ---- A.1 / A.2: announcement, heard by the addressed sender ------------------------------------
         const int Ld = ndigits(slots);
         const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(Ld * 8)));
         const double up_d = rx_d0 + p_a;                                  // simple_stack.py:82  (+p) at the start
         const double noise_d = up_d - p_a;                                // :166-167 noise = received - signal
         if (!(noise_d >= 0.0)) fl |= GW_FLAG_REFEXC;                      // :168 assert noisePower >= 0
-        bool ca_dirty = false, cx_dirty = false;
         const double ber_a = ber_cached(ca, ca_dirty, p_a, noise_d, ten_log_br);
         const bool granted = receive(m, ber_a, an, br, hdr_bits, (double)(Ld * 8) * coded_factor, fl);
         if (!(an.t_e >= an.stop)) fl |= GW_FLAG_REFEXC;
@@ -291,6 +343,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             }
         };
 
+        STAMP(3);
         // ---- A.3 / A.4: window at sender d, every data packet heard by the RRM -----------------------------------
         if (granted) {
             const double total = (double)slots * slot;                    // simple_stack.py:400
@@ -331,6 +384,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
                 if (!(cur < stopw)) break;
             }
         }
+        STAMP(4);
         // ---- A.5: remaining ticks up to the end of the step ------------------------------------------------
         ticks_upto(t_end, true);
         const uint32_t n_ticks = tau - tau0;
@@ -355,7 +409,8 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
                 o.y = nb[b + 4] | (nb[b + 5] << 8) | (nb[b + 6] << 16) | (nb[b + 7] << 24);
                 o.z = nb[b + 8] | (nb[b + 9] << 8) | (nb[b + 10] << 16) | (nb[b + 11] << 24);
                 o.w = nb[b + 12] | (nb[b + 13] << 8) | (nb[b + 14] << 16) | (nb[b + 15] << 24);
-                st_(st.qb, oq + 16u * w, o);
+                if (COOP) out_qb[w] = o;
+                else st_(st.qb, oq + 16u * w, o);
             }
         } else {
             GwTally ki = {0, 0, 0, 0, 0};
@@ -366,6 +421,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             st.qb[oq + (uint32_t)(2 * D)] = 1;
         }
 
+        STAMP(5);
         // ---- all-pairs, D <= 6 (rows in registers) and the any-D path (in memory) -------------------------------
         if (ROWS) {
             double rn[2 * NH];
@@ -385,20 +441,24 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             for (int h = 0; h < NH; ++h)
                 if (rn[2 * h] != rxv[h].x || rn[2 * h + 1] != rxv[h].y) st_(st.rxp, orx + 16u * h, make_double2(rn[2 * h], rn[2 * h + 1]));
         } else {
-            if (rx_d != rx_d0) st.rxp[(size_t)e * RP + d] = rx_d;
-            if (rx_r != rx_r0) st.rxp[(size_t)e * RP + RRM] = rx_r;
+            if (!COOP) {
+                if (rx_d != rx_d0) st_(st.rxp, ((size_t)e * RP + d) * 8u, rx_d);
+                if (rx_r != rx_r0) st_(st.rxp, ((size_t)e * RP + RRM) * 8u, rx_r);
+            }
             if (!COOP) {
                 for (int j = 0; j < D; ++j) {
                     if (j == d) continue;
-                    const double a0 = st.rxp[(size_t)e * RP + j];
+                    const double a0 = ld<double>(st.rxp, ((size_t)e * RP + j) * 8u);
                     const double a = heard(a0, link(RRM, j), link(d, j), n_data);
                     if (!(a >= 0.0)) fl |= GW_FLAG_REFEXC;
-                    if (a != a0) st.rxp[(size_t)e * RP + j] = a;
+                    if (a != a0) st_(st.rxp, ((size_t)e * RP + j) * 8u, a);
                 }
             }
         }
-        if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + d) * 16u, ca);
-        if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + D + d) * 16u, cx);
+        if (!COOP) {
+            if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + d) * 16u, ca);
+            if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + D + d) * 16u, cx);
+        }
 
         // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------------------
         const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
@@ -406,56 +466,57 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         int32_t r = last_abs - abs_d;
         last_abs = abs_d;
         r = r > 10 ? 10 : (r < -10 ? -10 : r);
-        st_(obs, (size_t)e << 2, (int32_t)(latest + c.counter_bound));
-        st_(reward, (size_t)e << 2, (float)r);
-        st_(done, (size_t)e, (uint8_t)dn);
-        st_(st.tw, o16, make_double2(t_end, wake));
-        st_(st.tk, o16, make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31)));
+        if (COOP) {
+            out_commit = true;
+            out_obs = (int32_t)(latest + c.counter_bound);
+            out_rew = (float)r;
+            out_tw = make_double2(t_end, wake);
+            out_tk = make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31));
+        } else {
+            st_(obs, (size_t)e << 2, (int32_t)(latest + c.counter_bound));
+            st_(reward, (size_t)e << 2, (float)r);
+            st_(done, (size_t)e, (uint8_t)dn);
+            st_(st.tw, o16, make_double2(t_end, wake));
+            st_(st.tk, o16, make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31)));
+        }
     }
-    if (live) publish_env_counters(st.sa, N, e, k_pop, k_deliv, k_bad, fl, 1u);
+    STAMP(6);
+    if (!COOP && live) publish_env_counters(st.sa, N, e, k_pop, k_deliv, k_bad, fl, 1u);
 
-    // ---- all-pairs, D = 8 / 16 / 32: groups of D lanes, one lane per listening radio ------------------------------
+    // ---- all-pairs, D = 8 / 16 / 32, second half: the listeners' updates (loads issued in front of the walk) ------------------
     if (COOP) {
-        constexpr int G = DT > 0 ? DT : 64;                       // lanes per env
-        constexpr int EPP = 64 / G;                               // envs per pass
-        const int lane = threadIdx.x;
-        const int j = lane % G;                                   // this lane's radio
-        const int act = (live && !bad) ? 1 : 0;
-        // (the walking lane's own two stores above -- rx[d], rx[RRM] -- touch other words than the listeners' here)
-        constexpr int PQ = G >= 4 ? 4 : G;                        // passes whose loads are in flight together
-#pragma unroll 1
-        for (int q0 = 0; q0 < G; q0 += PQ) {
-            int dd[PQ], nn[PQ], on[PQ];
-            uint32_t eq[PQ];
-            double a0[PQ], pa[PQ], pd[PQ];
+        // A lone wave issues an instruction every ~8 cycles, so this is written for instruction count: ONE shuffle per env (the
+        // walker's packet count), 32-bit offsets from the wave's base address, and the "reference would raise" bit -- never seen in
+        // practice -- straight to its env's flag word by whichever listener lane found it.
+        double* rx_wave = st.rxp + (size_t)e_wave * RP;
 #pragma unroll
-            for (int u = 0; u < PQ; ++u) {
-                const int src = (q0 + u) * EPP + lane / G;        // the lane that walked this group's env
-                dd[u] = __shfl(d, src);
-                nn[u] = __shfl(n_data, src);
-                on[u] = __shfl(act, src) && j != dd[u];
-                eq[u] = blockIdx.x * 64u + (uint32_t)src;
-                const uint32_t es = on[u] ? eq[u] : (blockIdx.x * 64u < N ? blockIdx.x * 64u : 0u);   // (a valid row for idle lanes)
-                const size_t row = (size_t)es * RP;
-                a0[u] = st.rxp[row + j];
-                pa[u] = PER_ENV ? st.prx_env[((size_t)es * R + RRM) * RP + j] : s_prx[RRM * R + j];
-                const int dr = on[u] ? dd[u] : 0;
-                pd[u] = PER_ENV ? st.prx_env[((size_t)es * R + dr) * RP + j] : s_prx[dr * R + j];
-            }
-#pragma unroll
-            for (int u = 0; u < PQ; ++u) {
-                uint32_t flj = 0;
-                if (on[u]) {
-                    const double a = heard(a0[u], pa[u], pd[u], nn[u]);
-                    if (!(a >= 0.0)) flj = GW_FLAG_REFEXC;
-                    if (a != a0[u]) st_(st.rxp, ((size_t)eq[u] * RP + j) * 8u, a);
-                }
-                // "the reference would raise" of any listener of the env: OR across the group, one atomic by its first lane
-#pragma unroll
-                for (int o = G >> 1; o > 0; o >>= 1) flj |= (uint32_t)__shfl_xor((int)flj, o);
-                if (j == 0 && flj) __hip_atomic_fetch_or(st.sa + (size_t)3 * N + eq[u], flj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < CNP; ++u) {
+            const uint32_t src = (uint32_t)(u * CEPP) + c_lane / CG;
+            const int nsrc = __shfl(n_data, (int)src);
+            if ((c_on >> u) & 1ull) {
+                const double a = heard(c_a0[u], c_pa[u], c_pd[u], nsrc);
+                if (a != c_a0[u]) st_(rx_wave, (size_t)c_off[u] * 8u, a);
+                if (!(a >= 0.0))
+                    __hip_atomic_fetch_or(st.sa + (size_t)3 * N + e_wave + src, (uint32_t)GW_FLAG_REFEXC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        STAMP(7);
+        // ---- the walking lane's own stores, last (its rx[d], rx[RRM] are other words than the listeners' above) ----
+        if (out_commit) {
+            if (rx_d != rx_d0) st_(st.rxp, ((size_t)e * RP + d) * 8u, rx_d);
+            if (rx_r != rx_r0) st_(st.rxp, ((size_t)e * RP + RRM) * 8u, rx_r);
+            if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + d) * 16u, ca);
+            if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + D + d) * 16u, cx);
+#pragma unroll
+            for (int w = 0; w < NWC; ++w) st_(st.qb, oq + 16u * w, out_qb[w]);
+            st_(obs, (size_t)e << 2, out_obs);
+            st_(reward, (size_t)e << 2, out_rew);
+            st_(done, (size_t)e, (uint8_t)dn);
+            st_(st.tw, o16, out_tw);
+            st_(st.tk, o16, out_tk);
+        }
+        if (live) publish_env_counters(st.sa, N, e, k_pop, k_deliv, k_bad, fl, 1u);
+        STAMP(8);
     }
 }
 

@@ -15,8 +15,15 @@ N, D = 65536, int(os.environ.get("STAMPS_D", "4"))
 # counter-based action stream, a reset every W + K steps, stamps taken on the timed indices only
 W, K = int(os.environ.get("STAMPS_W", "5")), int(os.environ.get("STAMPS_K", "20"))
 EXPLICIT = os.environ.get("STAMPS_EXPLICIT", "0") == "1"        # the generic kernel (ct_step.hip) instead of the default one
+LIVE = os.environ.get("STAMPS_LIVE", "0") == "1"                # the live-PHY kernel with per-env geometry (ct_step_dyn.hip)
 env = gymwipe_amd.VecCounterTrafficEnv(N, num_devices=D, start_time=float(os.environ.get("STAMPS_T0", "300.0")),
-                                       explicit_queue=EXPLICIT, per_env_stats=EXPLICIT)
+                                       explicit_queue=EXPLICIT, per_env_stats=EXPLICIT, per_env_geometry=LIVE)
+if LIVE:
+    rng = np.random.default_rng(3)
+    pos = np.zeros((N, D + 1, 2))
+    ang, rad = rng.uniform(0, 2 * np.pi, (N, D)), rng.uniform(1.0, 3.0, (N, D))
+    pos[:, :D, 0], pos[:, :D, 1] = rad * np.cos(ang), rad * np.sin(ang)
+    env.set_positions(pos)
 a_dev, a_dur = actions_torch(1234, 0, N, 0, W + K, D, device="cuda")
 names = ["0 issue table+state loads, write LDS", "1 barrier", "2 state landed (touch ip)", "3 unpack, LDS lookups, consts",
          "4 announcement tx_times", "5 announcement decode, t_end", "6 window loop", "7 tail ticks_to(t_end)",
@@ -24,6 +31,9 @@ names = ["0 issue table+state loads, write LDS", "1 barrier", "2 state landed (t
 if EXPLICIT:
     names = ["0 issue table+state loads, write LDS, barrier", "1 bad-action test, constants", "2 announcement", "3 queue record, lookups, prefetch",
              "4 window loop", "5 tail ticks", "6 other senders' queues", "7 noise states", "8 feedback values", "9 totals", "10 all stores"]
+if LIVE:
+    names = ["0 issue loads, write LDS, barrier", "1 action-dependent loads, scalars", "2 announcement", "3 window loop", "4 tail ticks, queue lengths, qb pack",
+             "5 rows in registers / walker's part", "6 lane groups' all-pairs pass", "7 walker's stores + counters"]
 NS = len(names) + 1
 rows = []
 rows_loop = []
@@ -67,7 +77,7 @@ per_launch_max = np.array([r.sum(axis=1).max() for r in rows])
 print("  slowest wave of a launch: mean %.0f  (the launch lasts at least this long)" % per_launch_max.mean())
 # window-loop cycles against the packet count of the wave's busiest lane: slope = cycles per packet iteration
 mp = np.concatenate(pops_rows)
-loop = d[:, 4 if EXPLICIT else 6]
+loop = d[:, 3 if LIVE else (4 if EXPLICIT else 6)]
 A = np.stack([mp, np.ones_like(mp)], axis=1).astype(np.float64)
 coef, *_ = np.linalg.lstsq(A, loop.astype(np.float64), rcond=None)
 print("  window loop ~= %.0f + %.0f x (packets of the busiest lane); busiest lane: median %d, p90 %d, max %d packets" % (coef[1], coef[0], np.median(mp), np.percentile(mp, 90), mp.max()))

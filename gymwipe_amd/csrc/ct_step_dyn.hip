@@ -108,12 +108,13 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
     constexpr bool PACKED = DT > 0;
     constexpr bool ROWS = DT > 0 && DT <= 6;                     // the env's rows in the walking lane's registers
     constexpr bool COOP = DT >= 8;                               // all-pairs part by groups of DT lanes
+    constexpr bool RXR = DT >= 16;                               // the RRM's received power from its mirror (GwState::rxr)
     const int D = DT > 0 ? DT : c.D;
     const int R = D + 1, RRM = D;
     constexpr int NWC = DT > 0 ? (2 * DT + 1 + 15) / 16 : 1;
-    constexpr int RPC = DT > 0 ? ((DT + 2) & ~1) : 2;            // gw_rp(R) at compile time
+    constexpr int RPC = DT > 0 ? gw_rp(DT + 1) : 2;              // row pitch at compile time (gw_internal.h: whole memory lines)
     const int RP = DT > 0 ? RPC : gw_rp(R);
-    constexpr int NH = RPC / 2;                                  // double2 chunks of a row
+    constexpr int NH = DT > 0 ? ((DT + 2) & ~1) / 2 : 1;         // double2 chunks of a row that hold radios
     const uint32_t N = n_envs;
     const uint32_t e = blockIdx.x * 64u + threadIdx.x;
     const bool live = e < N;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         // all D "sender i hears the RRM" cache entries: which one the step needs depends on the action, and a load issued
         // only once the action has arrived is a second memory round trip in front of the announcement's decision
 #pragma unroll
-        for (int i = 0; i < DT; ++i) cav[i] = ld<double2>(st.bcache, ((size_t)el * 2 * DT + i) * 16u);
+        for (int i = 0; i < DT; ++i) cav[i] = ld<double2>(st.bcache, ((size_t)el * 2 * DT + 2 * i) * 16u);
         if (PER_ENV) {
 #pragma unroll
             for (int h = 0; h < NH; ++h) pav[h] = ld<double2>(st.prx_env, olk + ((size_t)RRM * RP) * 8u + 16u * h);
@@ -171,9 +172,9 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
 #pragma unroll
         for (int i = 1; i < DT; ++i) { ca.x = (i == dq) ? cav[i].x : ca.x; ca.y = (i == dq) ? cav[i].y : ca.y; }
     } else {
-        ca = ld<double2>(st.bcache, ((size_t)el * 2 * D + dq) * 16u);
+        ca = ld<double2>(st.bcache, ((size_t)el * 2 * D + 2 * dq) * 16u);
     }
-    double2 cx = ld<double2>(st.bcache, ((size_t)el * 2 * D + D + dq) * 16u);   // (first needed at the first data packet)
+    double2 cx = ld<double2>(st.bcache, ((size_t)el * 2 * D + 2 * dq + 1) * 16u);   // (first needed at the first data packet)
     double2 pdv[ROWS && PER_ENV ? NH : 1];
     if (ROWS && PER_ENV) {
 #pragma unroll
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         }
     } else {
         rx_d0 = ld<double>(st.rxp, ((size_t)el * RP + dq) * 8u);
-        rx_r0 = ld<double>(st.rxp, ((size_t)el * RP + RRM) * 8u);
+        rx_r0 = RXR ? ld<double>(st.rxr, (size_t)el * 8u) : ld<double>(st.rxp, ((size_t)el * RP + RRM) * 8u);
         p_a = link(RRM, dq);
     }
     // the attenuation of a pair is one number (one model per unordered pair, physical.py:500-528; gw_create refuses an
@@ -456,8 +457,8 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             }
         }
         if (!COOP) {
-            if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + d) * 16u, ca);
-            if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + D + d) * 16u, cx);
+            if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + 2 * d) * 16u, ca);
+            if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + 2 * d + 1) * 16u, cx);
         }
 
         // ---- interpreter feedback (counter_traffic.py:85-112, envs/core.py:142-153) -----------------------
@@ -504,9 +505,12 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
         // ---- the walking lane's own stores, last (its rx[d], rx[RRM] are other words than the listeners' above) ----
         if (out_commit) {
             if (rx_d != rx_d0) st_(st.rxp, ((size_t)e * RP + d) * 8u, rx_d);
-            if (rx_r != rx_r0) st_(st.rxp, ((size_t)e * RP + RRM) * 8u, rx_r);
-            if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + d) * 16u, ca);
-            if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + D + d) * 16u, cx);
+            if (rx_r != rx_r0) {
+                st_(st.rxp, ((size_t)e * RP + RRM) * 8u, rx_r);
+                if (RXR) st_(st.rxr, (size_t)e * 8u, rx_r);
+            }
+            if (ca_dirty) st_(st.bcache, ((size_t)e * 2 * D + 2 * d) * 16u, ca);
+            if (cx_dirty) st_(st.bcache, ((size_t)e * 2 * D + 2 * d + 1) * 16u, cx);
 #pragma unroll
             for (int w = 0; w < NWC; ++w) st_(st.qb, oq + 16u * w, out_qb[w]);
             st_(obs, (size_t)e << 2, out_obs);
@@ -586,6 +590,7 @@ __global__ void ct_init_dyn_kernel(GwState st, GwDevConst c, double thermal)
     if (e >= N) return;
     const int D = c.D, R = D + 1, RP = gw_rp(R);
     for (int r = 0; r < RP; ++r) st.rxp[(size_t)e * RP + r] = r < R ? thermal : 0.0;
+    if (st.rxr) st.rxr[e] = thermal;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     if (st.bcache)
         for (int i = 0; i < 2 * D; ++i) { st.bcache[((size_t)e * 2 * D + i) * 2] = nan; st.bcache[((size_t)e * 2 * D + i) * 2 + 1] = 0.0; }

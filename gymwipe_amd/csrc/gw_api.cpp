@@ -454,7 +454,7 @@ int gw_create(const gw_config* cfg, gw_env** out)
     if (env->dyn) {
         const int RP = gw_rp(R);                            // rows of one env's radios, 16-byte aligned (gw_internal.h)
         TRY_ALLOC(st.rxp, N * RP);  TRY_ALLOC(d_prx, R * R);  TRY_ALLOC(d_pos, R * 2);  TRY_ALLOC(d_extra, R * R);
-        if (!explicit_q) TRY_ALLOC(st.bcache, N * 2 * D * 2);
+        if (!explicit_q) { TRY_ALLOC(st.bcache, N * 2 * D * 2);  TRY_ALLOC(st.rxr, N); }
         if (per_env_geo) { TRY_ALLOC(st.prx_env, N * R * RP);  TRY_ALLOC(st.pos_env, N * R * 2); }
         if (per_env_geo && explicit_q) TRY_ALLOC(st.talk, N);   // (default queue mode: the mask lives in spare bytes of the qb record)
         st.prx_tab = d_prx; st.pos_tab = d_pos; st.extra_tab = d_extra;

@@ -104,17 +104,28 @@ struct GwState {
     const double* extra_tab; // [R][R]  custom attenuation per pair, dB
     double*   prx_env;    // [N][R][RP] per-env link powers, row = talker (GW_CFG_PER_ENV_GEOMETRY), else nullptr
     double*   pos_env;    // [N][R][2]  per-env positions
-    double*   bcache;     // [N][2D][2] {noise power, BER} last evaluated for: sender i hearing the RRM (entry i), the RRM
-                          //            hearing sender i (entry D + i); key NaN = empty.  BpskMcs.calculateBitErrorRate is two
+    double*   bcache;     // [N][D][2][2] {noise power, BER} last evaluated for: sender i hearing the RRM (entry 2i), the RRM
+                          //            hearing sender i (entry 2i + 1: the same 32 bytes, one memory line); key NaN = empty.  BpskMcs.calculateBitErrorRate is two
                           //            log10, three pow and a sqrt in f64 (physical.py:25-58,208-212): ~350 instructions that
                           //            a step would otherwise spend twice; received powers settle on a few residue values.
+    double*   rxr;        // [N]        default queue mode: a MIRROR of rxp[e][RRM], the RRM's own received power, which the walking lane
+                          //            needs every step -- above 16 radios it is the only word of the rxp row's second memory line
+                          //            that a step reads (the row's authoritative copy is written along with it, when it changes)
     uint64_t* talk;       // [N]        bit r: radio r has transmitted, i.e. its attenuation models exist (physical.py:500-528
                           //            creates a pair's model at first use) -- what Position.set's keep-stale rules ask
 };
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-constexpr int gw_rp(int R) { return (R + 1) & ~1; }        // doubles per row of rxp / prx_env
+// doubles per row of rxp / prx_env (the row pitch).  Rows are read as whole 128-byte memory lines, and on this GPU the live-PHY
+// step is bound by the NUMBER of lines a CU has in flight times their latency (in-kernel stamps): so a row never
+// straddles a line -- up to 16 radios the pitch is the next power of two (one line holds 16 / pitch whole rows), above that a
+// multiple of 16 doubles, with the D senders' entries in the first lines and the RRM's (index D, read by the walking lane only)
+// behind them: at D = 16 the lane groups' row reads are ONE aligned line each (pitch 18 = 144 bytes took two or three).
+constexpr int gw_rp(int R)
+{
+    return R <= 2 ? 2 : (R <= 4 ? 4 : (R <= 8 ? 8 : (R <= 16 ? 16 : ((R + 15) & ~15))));
+}
 
 // byte offsets inside GwState::blob (the default step kernel's tables; see ct_step_sfx.hip)
 struct GwBlobLayout {

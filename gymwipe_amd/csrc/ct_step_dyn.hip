@@ -351,6 +351,70 @@ __global__ __launch_bounds__(64) void ct_step_live_kernel(GW_LEAD_PARAMS, int32_
             const double stopw = t_r + total;                             // :401
             double cur = t_r;
             ticks_upto(cur, false);                                       // the MAC's process initialisation is URGENT
+            // ---- the window loop, straight-line form (the default kernel's, ct_step_sfx.hip: a lone wave per SIMD issues one
+            //      instruction per ~8 cycles, and the wave lasts as long as its busiest lane's 8-9 packets; in-kernel stamps put
+            //      the general loop below at 1 900 + 1 700 cycles per packet of that lane).  Taken when tick jumps apply, the exact
+            //      fast forms of fmod and division hold up to t_end and t_r >= 2 (t_end - t_r): then a packet's header end and
+            //      stop time ARE t_s + hd and t_s + (hd + pd) (Sterbenz), the completion event fires at stop, and the reference's
+            //      `not t.completed` case cannot arise.  The live PHY's part stays per packet: the RRM's (+p, -p) residue and the
+            //      BER at that noise (through the link's cache) decide every reception.  One exit condition; the general loop
+            //      takes over on an empty queue (it waits for the tick) or a breakpoint-ring lookup.
+            bool more = true;
+            {
+                const double span = t_end - t_r;
+                const bool straight = span_ok && mult_d != 0u && m.fast_fmod && m.fast_div && t_end < m.fmod_limit && t_r >= span + span;
+                if (straight && len_d != 0u) {
+                    auto head = [&](uint32_t len, uint32_t tk_now, bool& deep) {
+                        const uint32_t age = __umul24(len + mult_d - 1u, inv16_d) >> 16;      // gw_ceil_div
+                        const uint32_t ht = tk_now - age;                 // tick of the head packet
+                        const bool older = ht < bpc.t0;
+                        deep = older && ht < bpp.t0;                      // > 2 resets inside the queue's span
+                        return base_bytes + gw_min_u32((older ? bpp.c0 : bpc.c0) + (ht - (older ? bpp.t0 : bpc.t0)), bound);
+                    };
+                    bool deep = false;
+                    uint32_t chk = 0, pops = 0;
+                    uint32_t s = head(len_d, tau, deep);
+                    bool go = !deep && (stopw - cur) > gw_fast_div((double)(s * 8u), m.dr, m.rcp_dr);       // :418-420
+                    while (go) {
+                        const int pay = (int)s - mh;
+                        const double pd = gw_fast_div((double)(pay * 8), m.dr, m.rcp_dr);
+                        TxTimes x;
+                        x.t_s = cur + (m.slot - gw_fast_fmod_lo(cur, m.slot, c.inv_slot_lo));
+                        x.t_h = x.t_s + hd;
+                        x.stop = x.t_s + (hd + pd);
+                        x.t_e = x.stop;
+                        const double up = rx_r + p_x;
+                        const double noise = up - p_x;
+                        chk |= !(noise >= 0.0) ? (uint32_t)GW_FLAG_REFEXC : 0u;
+                        const double ber_x = ber_cached(cx, cx_dirty, p_x, noise, ten_log_br);
+                        uint32_t unused = 0;
+                        const bool ok = receive(m, ber_x, x, br, hdr_bits, (double)(pay * 8) * coded_factor, unused);
+                        rx_r = up + (-p_x);
+                        k_deliv += ok ? 1u : 0u;                          // devices.py:163-168, counter_traffic.py:75-80
+                        rvm |= ok ? (1u << d) : 0u;
+                        dn = (ok && pv == c.counter_bound) ? 1u : dn;
+                        uint32_t nj = 0;
+                        double wj = wake;
+                        bool tiej = false, sane = false;
+                        gw_tick_jump_lo(wake, x.t_e, delta, c.inv_interval_lo, true, &nj, &wj, &tiej, &sane);
+                        chk |= (sane ? 0u : (uint32_t)GW_FLAG_INTERNAL) | (tiej ? (uint32_t)GW_FLAG_TIE : 0u);
+                        len_d = gw_min_u32(len_d - 1u + __umul24(nj, mult_d), (uint32_t)GW_QUEUE_CAP);
+                        tau += nj;
+                        wake = wj;
+                        cur = x.t_e;
+                        pops++;
+                        bool deep_n = false;
+                        s = head(len_d, tau, deep_n);
+                        go = cur < stopw && len_d != 0u && !deep_n && (stopw - cur) > gw_fast_div((double)(s * 8u), m.dr, m.rcp_dr);
+                    }
+                    (void)head(len_d, tau, deep);
+                    more = cur < stopw && (len_d == 0u || deep);
+                    fl |= chk | ((pops && !(cur < t_end)) ? (uint32_t)GW_FLAG_CARRY : 0u);
+                    k_pop += pops;
+                    n_data += (int)pops;
+                }
+            }
+            if (more)
             for (;;) {
                 if (len_d == 0) {                                         // :409-416
                     if (mult_d != 0u && wake < stopw) {

@@ -636,6 +636,71 @@ def test_parity_at_large_simulated_times(t0, explicit):
         assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the rollout")
 
 
+@pytest.mark.parametrize("D,N", [(2, 1), (3, 63), (4, 65), (4, 1000), (8, 193), (16, 130)])
+def test_generic_kernel_two_wave_form_ragged_sizes_bad_actions_and_totals(D, N):
+    """The generic kernel at its default block runs as TWO waves per 64 envs (ct_step.hip: the walker and the helper that
+    ticks the other senders' queues and writes the noise-state record).  Sizes that leave the last workgroup ragged, every
+    templated sender count, invalid actions in some lanes (the helper must skip exactly the envs the walker skips), per-env
+    counters that both waves add to, and the wave totals -- all against the oracle, plus the same run with GW_NO_SPLIT."""
+    import torch
+    from gymwipe_amd import _native as nat
+    K = 40
+    dev, dur = action_stream(900 + D + N, K, N, D)
+    bad_at = {7: (0, D), 19: (N - 1, -1), 23: (N // 2, D + 3)}         # step -> (env, invalid device)
+    results = []
+    for no_split in (False, True):
+        if no_split:
+            os.environ["GW_NO_SPLIT"] = "1"
+        try:
+            env, orc = _mk(N, D, explicit=True)
+            assert (env.reset().cpu().numpy() == orc.reset()).all()
+            n_bad = 0
+            for k in range(K):
+                if k and k % 16 == 0:
+                    assert (env.reset().cpu().numpy() == orc.reset()).all()
+                dk, uk = dev[k].copy(), dur[k].copy()
+                skip = None
+                if k in bad_at:
+                    skip, dk[bad_at[k][0]] = bad_at[k][0], bad_at[k][1]
+                    n_bad += 1
+                o, r, d, _ = env.step({"device": torch.from_numpy(dk), "duration": torch.from_numpy(uk)})
+                if skip is None:
+                    oo, orr, od = orc.step(dk, uk)
+                    assert (o.cpu().numpy() == oo).all() and (r.cpu().numpy() == orr).all() and (d.cpu().numpy() == od).all(), k
+                else:
+                    # the oracle takes valid actions only.  The skipped env must have kept its state (= the oracle's, which has
+                    # not stepped yet); then the oracle steps everyone, and the GPU side catches up by a second call in which
+                    # ONLY the skipped env has a valid action (envs are independent: one call later makes no difference)
+                    before = {f: env.get_state(f)[skip].copy() for f in ("now", "counter", "qlen", "queue")}
+                    assert env.get_state("flags")[skip] & nat.FLAG_BADACT
+                    for f, v in before.items():
+                        assert (orc.get(f)[skip] == v).all(), (f, k)
+                    env.clear_flags()
+                    o1, r1 = o.cpu().numpy().copy(), r.cpu().numpy().copy()     # (step() returns the handle's own output tensors)
+                    dk[skip] = 0
+                    orc_o = orc.step(dk, uk)
+                    o2, r2, d2, _ = env.step({"device": torch.from_numpy(np.where(np.arange(N) == skip, 0, -1).astype(np.int32)),
+                                              "duration": torch.from_numpy(uk)})     # only the skipped env steps now
+                    n_bad += N - 1
+                    env.clear_flags()
+                    assert o2.cpu().numpy()[skip] == orc_o[0][skip] and r2.cpu().numpy()[skip] == orc_o[1][skip]
+                    mask = np.arange(N) != skip
+                    assert (o1[mask] == orc_o[0][mask]).all() and (r1[mask] == orc_o[1][mask]).all(), k
+                if (k + 1) % 8 == 0:          # (flags aside: the bad-action bits were cleared on the GPU side, with whatever else was set)
+                    assert_state_equal(env, orc, tuple(f for f in STATE_FIELDS if f != "flags") + STAT_FIELDS,
+                                       where="D=%d N=%d step %d" % (D, N, k))
+            st = env.stats()
+            assert st["bad_actions"] == n_bad
+            for name, f in (("transmissions", "n_tx"), ("delivered", "n_delivered"), ("appended", "n_appended"),
+                            ("popped", "n_popped"), ("dropped", "n_dropped")):
+                assert st[name] == int(orc.get(f).sum()), name
+            results.append({f: env.get_state(f).copy() for f in ("now", "queue", "rx_power", "counter")})
+        finally:
+            os.environ.pop("GW_NO_SPLIT", None)
+    for f in results[0]:
+        assert (results[0][f].view(np.uint8) == results[1][f].view(np.uint8)).all(), f
+
+
 @pytest.mark.parametrize("block", ["16", "32", "128", "256"])
 def test_parity_with_other_workgroup_sizes(block, monkeypatch):
     """GW_BLOCK (read at gw_create) changes the launch shape of the generic step kernel and, below 64 threads, the way its

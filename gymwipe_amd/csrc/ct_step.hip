@@ -826,11 +826,20 @@ int gw_launch_step(const GwState& st, const int32_t* device, const int32_t* dura
             hipLaunchKernelGGL((ct_step_kernel<DT_, false, false>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, \
                                st, device, duration, obs, reward, done);                                        \
     } while (0)
-    if (st.rxp) {                                        // live PHY (open noise-state set / per-env geometry): runtime-D instantiation
-        if (st.pe_stats)
-            hipLaunchKernelGGL((ct_step_kernel<0, true, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, device, duration, obs, reward, done);
-        else
-            hipLaunchKernelGGL((ct_step_kernel<0, false, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, device, duration, obs, reward, done);
+    if (st.rxp) {                                        // live PHY (open noise-state set / per-env geometry)
+#define GW_LAUNCH_DYN(DT_)                                                                                       \
+    do {                                                                                                        \
+        if (st.pe_stats)                                                                                        \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, true, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, device, duration, obs, reward, done); \
+        else                                                                                                    \
+            hipLaunchKernelGGL((ct_step_kernel<DT_, false, true>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, device, duration, obs, reward, done); \
+    } while (0)
+        switch (st.D) {                                  // the queue records in registers for the usual sender counts
+        case 4:  GW_LAUNCH_DYN(4); break;
+        case 16: GW_LAUNCH_DYN(16); break;
+        default: GW_LAUNCH_DYN(0); break;
+        }
+#undef GW_LAUNCH_DYN
         return check_launch();
     }
     switch (st.D) {

@@ -60,11 +60,18 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
                                                        float* __restrict__ reward, double* __restrict__ angle_deg)
 {
     __shared__ double s_new0[NEW0 * 64], s_new1[NEW1 * 64];
+    // the noise-state transitions and the BER per (listener, talker, state): looked up for every radio at every transmission
+    // (a window of the sensor's queue is dozens of them) -- from LDS, not a dependent global round trip apiece
+    __shared__ uint8_t s_trans[CR * CR * S];
+    __shared__ double s_ber[CR * CR * S];
+    for (int i = threadIdx.x; i < CR * CR * S; i += blockDim.x) { s_trans[i] = c.trans[i]; s_ber[i] = c.ber[i]; }
+    __syncthreads();
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= c.N) return;
     double* col0 = s_new0 + (threadIdx.x & 63);
     double* col1 = s_new1 + (threadIdx.x & 63);
-    const GwDevConst& k = *c.cst;
+    // (the handle's constants by value through the constant address space: scalar loads the compiler may hoist and keep)
+    const GwDevConst k = *(const GW_AS_CONST GwDevConst*)c.cst;
     Lane L;
     L.now = c.now[e]; L.wake = c.wake[e]; L.u = c.u[e]; L.ang = c.ang[e]; L.ktick = c.ktick[e];
     for (int i = 0; i < 4; ++i) L.x[i] = c.x[e * 4 + i];
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
         auto all_hear = [&](int from) {
 #pragma unroll
             for (int j = 0; j < CR; ++j)
-                if (j != from) L.rxs[j] = c.trans[((size_t)j * CR + from) * S + L.rxs[j]];   // j is a compile-time index here
+                if (j != from) L.rxs[j] = s_trans[(j * CR + from) * S + L.rxs[j]];   // j is a compile-time index here
         };
 
         const double t_a = L.now;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
         const TxTimes an = tx_times(m, t_a, hd, m.over_rate((double)(Ld * 8)));
         L.ntx++;
         all_hear(CRRM);
-        const bool granted = receive(m, c.ber[((size_t)d * CR + CRRM) * S + pick(L.rxs, d)], an, br, hdr_bits,
+        const bool granted = receive(m, s_ber[(d * CR + CRRM) * S + pick(L.rxs, d)], an, br, hdr_bits,
                                      (double)(Ld * 8) * k.coded_factor, L.fl);
         const double t_r = an.t_e;
         const double t_end = t_r + (double)(slots + 1) * slot;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(64) void ctrl_step_kernel(GwCtrlDev c, const int32_
                 const TxTimes x = tx_times(m, cur, hd, pd);
                 L.ntx++;
                 all_hear(d);
-                const bool ok = receive(m, c.ber[((size_t)dst * CR + d) * S + pick(L.rxs, dst)], x, br, hdr_bits,
+                const bool ok = receive(m, s_ber[(dst * CR + d) * S + pick(L.rxs, dst)], x, br, hdr_bits,
                                         (double)(((int)sz - mh) * 8) * k.coded_factor, L.fl);
                 if (!(x.t_e < t_end)) L.fl |= GW_FLAG_CARRY;
                 ticks_until(x.t_e, false);                                      // ticks during the transmission

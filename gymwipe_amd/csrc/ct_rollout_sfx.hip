@@ -525,12 +525,346 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl, (uint32_t)K);
 }
 
+// ---- the step-synchronous form (compile-time sender counts) --------------------------------------------------------------
+// The event loop above was built when a data packet cost as much as an announcement (one pass of a ~140-instruction body
+// either way) and letting lanes run ahead of each other evened the work out.  Since the window loop has a straight-line form
+// (ct_step_sfx.hip: ~45 instructions per packet, every per-packet decision settled for the step up front), a packet is a third
+// of an announcement, and the lock-step of whole steps costs less than the event loop's ~60 exec-mask regions per pass: here
+// every lane takes step k together -- announcement, window (straight line, general loop where that declines), feedback -- with
+// the env's state in registers across all K steps, queue lengths of the senders not addressed and the ticks behind a window
+// lazy exactly as above.  Same results bit for bit (the tests run both forms against the oracle; GW_ROLLOUT_EVENT_LOOP=1
+// selects the event loop).
+template <int DT, int MODE>
+__global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevConst c, int K, int Kp,
+                                                            const uint16_t* __restrict__ actions,
+                                                            uint8_t* __restrict__ feedback)
+{
+    static_assert(DT > 0, "the any-D rollout keeps the event loop");
+    constexpr int D = DT, R = D + 1, RRM = D;
+    constexpr int NWC = (2 * DT + 1 + 15) / 16;
+    constexpr int S = GW_MAX_NSTATES;
+    const uint32_t N = (uint32_t)st.N;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+
+    constexpr int TRANS_B = ((DT + 1) * (DT + 1) * S + 15) / 16 * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_trans[TRANS_B];
+    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DT * S];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DT * S];
+    {
+        const int n_tr = (R * R * S + 15) >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;
+        for (int i = threadIdx.x; i < n_tr; i += blockDim.x) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)i << 4)) = ld<uint4>(st.trans, (uint32_t)i << 4);
+        for (int i = threadIdx.x; i < n_be; i += blockDim.x) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(s_ber) + ((uint32_t)i << 4)) = ld<uint4>(st.ber2, (uint32_t)i << 4);
+        for (int i = threadIdx.x; i < n_cl; i += blockDim.x) *reinterpret_cast<uint4*>(s_cls + ((uint32_t)i << 4)) = ld<uint4>(st.cls2, (uint32_t)i << 4);
+    }
+    __syncthreads();
+    if (e >= N) return;
+
+    // ---- state -> registers ----
+    const uint32_t o16 = e << 4, oq = e * (16u * NWC);
+    const uint4 ip = ld<uint4>(st.ip, o16);
+    const double2 tw = ld<double2>(st.tw, o16);
+    const uint4 tk = ld<uint4>(st.tk, o16);
+    uint32_t len[DT], tb[DT], sta[DT + 1];
+    {
+        uint4 qw[NWC];
+#pragma unroll
+        for (int w = 0; w < NWC; ++w) qw[w] = ld<uint4>(st.qb, oq + 16u * w);
+#pragma unroll
+        for (int i = 0; i < DT; ++i) len[i] = (word_of(qw[i >> 4], (i >> 2) & 3) >> ((i & 3) * 8)) & 0xffu;
+#pragma unroll
+        for (int j = 0; j < DT + 1; ++j) sta[j] = (word_of(qw[(DT + j) >> 4], ((DT + j) >> 2) & 3) >> (((DT + j) & 3) * 8)) & 0xffu;
+    }
+    double now = tw.x, wake = tw.y;
+    uint32_t tau = tk.x;
+    const uint32_t nbp = tk.y;
+    GwBp bpc, bpp;
+    bpc.t0 = ip.x; bpc.c0 = ip.y;
+    bpp.t0 = ip.z; bpp.c0 = ip.w;
+    const GwBp* hist = st.bph + ((size_t)e << 7);
+    uint32_t rvm = tk.z;
+    int32_t last_abs = (int32_t)(tk.w & 0x7fffffffu);
+    uint32_t dn = tk.w >> 31;
+
+    constexpr bool FAST = MODE >= 1, NOLIM = MODE == 2;
+    const StepMathT<FAST, NOLIM> m(c);
+    const double slot = c.slot, br = c.bit_rate, hd = c.hdr_dur, hdr_bits = c.hdr_bits, interval = c.counter_interval;
+    const double inv_interval = c.inv_interval, tie_filter = c.tie_filter, coded_factor = c.coded_factor;
+    const bool fast_ticks = FAST || c.fast_ticks != 0;
+    const bool idem = c.idem_states != 0;
+    const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
+    const int mh = c.mac_hdr, pv = c.payload_value;
+    uint32_t mult[DT], term[DT], inv16[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) { mult[i] = (uint32_t)c.mult[i]; term[i] = c.term[i]; inv16[i] = c.inv16[i]; }
+#pragma unroll
+    for (int i = 0; i < DT; ++i) tb[i] = tau;
+
+    Tally kt = {0, 0, 0, 0, 0};
+    uint32_t k_bad = 0, fl = 0;
+    uint32_t fbw = 0;
+    int k = 0;
+    const uint16_t* act = actions + (size_t)e * Kp;
+    uint8_t* fbp = feedback + (size_t)e * Kp;
+    uint4 aw = ld<uint4>(act, 0);   // actions of steps 0..7
+
+    auto put_feedback = [&](uint32_t byte) {
+        fbw |= byte << ((k & 3) * 8);
+        if ((k & 3) == 3 || k == K - 1) { st_(fbp, (uint32_t)(k & ~3), fbw); fbw = 0; }
+        k++;
+        if ((k & 7) == 0 && k < K) aw = ld<uint4>(act, (uint32_t)k * 2u);                // next 8 actions
+    };
+
+    while (k < K) {
+        // ---- start of step k (counter_traffic.py:146-158) ----
+        const uint32_t a = (word_of(aw, (k & 7) >> 1) >> ((k & 1) * 16)) & 0xffffu;
+        const int d = (int)(a & 0xffu);
+        const int du = (int)(a >> 8);
+        if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
+            fl |= GW_FLAG_BADACT;                    // env untouched, feedback repeats the current values
+            k_bad++;
+            put_feedback((uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | (10u << 2) | (dn << 7));
+            continue;
+        }
+        uint32_t l0 = 0, t0 = 0, s_d_old = 0, mult_d = 0, inv16_d = 65536u;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = inv16[i]; s_d_old = sta[i]; }
+        uint32_t len_d = gw_len_after_ticks(l0, tau - t0, mult_d, kt);          // the addressed queue, up to date
+        const int slots = du * c.duration_factor;                               // counter_traffic.py:149
+        const int Ld = ndigits(slots);
+        const bool cls_valid = NOLIM || now < c.cls_limit;
+        const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];  // d after hearing the RRM
+#pragma unroll
+        for (int i = 0; i < D; ++i) if (i == d) sta[i] = s_d;
+        // ---- A.1 / A.2: announcement ----
+        const TxTimes an = tx_times(m, now, hd, m.over_rate((double)(Ld * 8)));
+        kt.tx++;
+        const bool granted = decode(m, (uint32_t)s_cls[(uint32_t)(d * S) + s_d], cls_valid, s_ber[(uint32_t)(d * S) + s_d], an, br, hdr_bits,
+                                    (double)(Ld * 8) * coded_factor, fl);
+        const double t_r = an.t_e;
+        const double t_end = t_r + (double)(slots + 1) * slot;                  // simple_stack.py:557-558
+        uint32_t s_r = sta[RRM];
+        uint32_t n_data = 0;
+
+        // counter ticks with wake < t (or <= t): the running sum four at a time, or one jump where the step qualifies
+        auto ticks_to = [&](double t, bool inclusive) {
+            uint32_t kk = 0;
+            for (;;) {
+                const double w1 = wake + interval, w2 = w1 + interval, w3 = w2 + interval, w4 = w3 + interval;
+                const bool b0 = inclusive ? (wake <= t) : (wake < t);
+                const bool b1 = inclusive ? (w1 <= t) : (w1 < t);
+                const bool b2 = inclusive ? (w2 <= t) : (w2 < t);
+                const bool b3 = inclusive ? (w3 <= t) : (w3 < t);
+                const double last = b3 ? w3 : (b2 ? w2 : (b1 ? w1 : wake));
+                if (inclusive && b0 && last == t) fl |= GW_FLAG_TIE;
+                kk += (uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3;
+                wake = b3 ? w4 : (b2 ? w3 : (b1 ? w2 : (b0 ? w1 : wake)));
+                if (!b3) break;
+            }
+            tau += kk;
+            len_d = gw_len_after_ticks(len_d, kk, mult_d, kt);
+        };
+        double delta = 0.0;
+        const bool span_ok = fast_ticks && gw_tick_span_ok(wake, t_end, interval, &delta);
+        auto ticks_upto = [&](double t, bool inclusive) {
+            uint32_t nj = 0;
+            double wj = wake;
+            bool tiej = false, sane = false;
+            gw_tick_jump_lo(wake, t, delta, c.inv_interval_lo, inclusive, &nj, &wj, &tiej, &sane);
+            if (span_ok && sane) {
+                wake = wj;
+                tau += nj;
+                if (tiej) fl |= GW_FLAG_TIE;
+                len_d = gw_len_after_ticks(len_d, nj, mult_d, kt);
+            } else {
+                ticks_to(t, inclusive);
+            }
+        };
+
+        if (granted) {
+            // ---- A.3 / A.4: window at sender d (simple_stack.py:397-434) ----
+            const double stopw = t_r + (double)slots * slot;                    // :400-401
+            double cur = t_r;
+            ticks_upto(cur, false);                   // (covers the ticks since the previous window closed too: counting is cumulative)
+            const uint32_t s_r1 = s_trans[(uint32_t)((RRM * R + d) * S) + s_r];            // the RRM after one packet of d
+            const double ber_x1 = s_ber[(uint32_t)((D + d) * S) + s_r1];
+            const uint32_t cls_x1 = s_cls[(uint32_t)((D + d) * S) + s_r1];
+            bool more = true;
+            uint32_t pops = 0;
+            {
+                // the straight-line form: preconditions and reasoning in ct_step_sfx.hip
+                const double span = t_end - t_r;
+                const bool straight = span_ok && mult_d != 0u && idem && cls_valid && cls_x1 != (uint32_t)GW_CLS_COMPUTE &&
+                                      (FAST || (m.fast_fmod && m.fast_div)) && (NOLIM || t_end < m.fmod_limit) && t_r >= span + span;
+                if (straight && len_d != 0u) {
+                    auto head = [&](uint32_t ln, uint32_t tk_now, bool& deep) {
+                        const uint32_t age = __umul24(ln + mult_d - 1u, inv16_d) >> 16;   // gw_ceil_div
+                        const uint32_t ht = tk_now - age;
+                        const bool older = ht < bpc.t0;
+                        deep = older && ht < bpp.t0;
+                        return base_bytes + gw_min_u32((older ? bpp.c0 : bpc.c0) + (ht - (older ? bpp.t0 : bpc.t0)), bound);
+                    };
+                    bool deep = false;
+                    uint32_t chk = 0;
+                    uint32_t sz = head(len_d, tau, deep);
+                    bool go = !deep && (stopw - cur) > gw_fast_div((double)(sz * 8u), m.dr, m.rcp_dr);
+                    while (go) {
+                        const double pd = gw_fast_div((double)(((int)sz - mh) * 8), m.dr, m.rcp_dr);
+                        const double t_s = cur + (m.slot - gw_fast_fmod_lo(cur, m.slot, c.inv_slot_lo));
+                        const double t_e = t_s + (hd + pd);
+                        uint32_t nj = 0;
+                        double wj = wake;
+                        bool tiej = false, sane = false;
+                        gw_tick_jump_lo(wake, t_e, delta, c.inv_interval_lo, true, &nj, &wj, &tiej, &sane);
+                        chk |= (sane ? 0u : (uint32_t)GW_FLAG_INTERNAL) | (tiej ? (uint32_t)GW_FLAG_TIE : 0u);
+                        len_d = gw_min_u32(len_d - 1u + __umul24(nj, mult_d), (uint32_t)GW_QUEUE_CAP);
+                        tau += nj;
+                        wake = wj;
+                        cur = t_e;
+                        pops++;
+                        bool deep_n = false;
+                        sz = head(len_d, tau, deep_n);
+                        go = cur < stopw && len_d != 0u && !deep_n && (stopw - cur) > gw_fast_div((double)(sz * 8u), m.dr, m.rcp_dr);
+                    }
+                    (void)head(len_d, tau, deep);
+                    more = cur < stopw && (len_d == 0u || deep);
+                    fl |= chk | ((pops && !(cur < t_end)) ? (uint32_t)GW_FLAG_CARRY : 0u);
+                }
+            }
+            if (pops) {                                                         // devices.py:163-168, counter_traffic.py:75-80
+                const bool okx = cls_x1 == (uint32_t)GW_CLS_OK;
+                kt.pop += pops;
+                kt.tx += pops;
+                n_data += pops;
+                s_r = s_r1;
+                kt.deliv += okx ? pops : 0u;
+                rvm |= okx ? (1u << d) : 0u;
+                dn = (okx && pv == c.counter_bound) ? 1u : dn;
+            }
+            if (more)
+            for (;;) {
+                if (len_d == 0u) {                                              // :409-416
+                    if (mult_d != 0u && wake < stopw) {
+                        cur = wake;
+                        wake = wake + interval;
+                        tau++;
+                        len_d = gw_len_after_ticks(0u, 1u, mult_d, kt);
+                    } else break;
+                }
+                const uint32_t age = gw_ceil_div(len_d, mult_d, inv16_d);
+                const uint32_t sz = base_bytes + gw_tick_value(tau - age, bpc, bpp, nbp, hist, bound);
+                const double need = m.over_rate((double)(sz * 8u));             // messages.py:67-75
+                if (!((stopw - cur) > need)) break;                             // :418-420
+                len_d--;                                                        // :425
+                kt.pop++;
+                const int pay = (int)sz - mh;
+                const TxTimes x = tx_times(m, cur, hd, m.over_rate((double)(pay * 8)));
+                kt.tx++;
+                n_data++;
+                s_r = s_trans[(uint32_t)((RRM * R + d) * S) + s_r];             // the RRM hears sender d (again)
+                const bool ok = decode(m, (uint32_t)s_cls[(uint32_t)((D + d) * S) + s_r], cls_valid, s_ber[(uint32_t)((D + d) * S) + s_r], x, br,
+                                       hdr_bits, (double)(pay * 8) * coded_factor, fl);
+                kt.deliv += ok ? 1u : 0u;
+                rvm |= ok ? (1u << d) : 0u;
+                dn = (ok && pv == c.counter_bound) ? 1u : dn;
+                fl |= !(x.t_e < t_end) ? (uint32_t)GW_FLAG_CARRY : 0u;
+                ticks_upto(x.t_e, true);                                        // ticks are older events than the MAC's resume
+                cur = x.t_e;
+                if (!(cur < stopw)) break;                                      // window timeout already processed
+            }
+        }
+
+        // ---- close the step: A.5 lazily (the ticks up to t_end are counted by the next step's first count); what must not be
+        //      lost is the diagnostic bit for a tick falling EXACTLY on t_end (see the event loop above) ----
+        {
+            const double dd = t_end - wake;
+            if (dd >= 0.0) {
+                const double q = dd * inv_interval;
+                if (!(fabs(q - rint(q)) > tie_filter) || !(wake >= 0.0625) || !(wake < 2097152.0)) {
+                    for (double w = wake; w <= t_end; w = w + interval)
+                        if (w == t_end) fl |= GW_FLAG_TIE;
+                }
+            }
+        }
+        bool all_term = true;
+#pragma unroll
+        for (int i = 0; i < D; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i == d) { len[i] = len_d; tb[i] = tau; }
+        if (!all_term) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                if (i == d) continue;
+                uint32_t si = s_trans[(uint32_t)((i * R + RRM) * S) + sta[i]];  // heard the announcement
+                for (uint32_t n = 0; n < n_data; ++n) {                          // ... and d's data
+                    const uint32_t s2 = s_trans[(uint32_t)((i * R + d) * S) + si];
+                    if (s2 == si) break;
+                    si = s2;
+                }
+                sta[i] = si;
+            }
+        }
+        sta[RRM] = s_r;
+        const int32_t latest = pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u));
+        const int32_t abs_d = latest < 0 ? -latest : latest;
+        int32_t r = last_abs - abs_d;
+        last_abs = abs_d;
+        r = r > 10 ? 10 : (r < -10 ? -10 : r);
+        now = t_end;
+        put_feedback((uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | ((uint32_t)(r + 10) << 2) | (dn << 7));
+    }
+
+    // ---- catch up: ticks up to the end of the last step, every queue to the final tick ----
+    {
+        uint32_t kk = 0;
+        while (wake <= now) { if (wake == now) fl |= GW_FLAG_TIE; wake = wake + interval; kk++; }
+        tau += kk;
+#pragma unroll
+        for (int i = 0; i < D; ++i) len[i] = gw_len_after_ticks(len[i], tau - tb[i], mult[i], kt);
+    }
+    {
+        uint32_t nb[16 * NWC];
+#pragma unroll
+        for (int b = 0; b < 16 * NWC; ++b) nb[b] = 0u;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) nb[i] = len[i];
+#pragma unroll
+        for (int j = 0; j < DT + 1; ++j) nb[DT + j] = sta[j];
+#pragma unroll
+        for (int w = 0; w < NWC; ++w) {
+            const int b = 16 * w;
+            uint4 o;
+            o.x = nb[b + 0] | (nb[b + 1] << 8) | (nb[b + 2] << 16) | (nb[b + 3] << 24);
+            o.y = nb[b + 4] | (nb[b + 5] << 8) | (nb[b + 6] << 16) | (nb[b + 7] << 24);
+            o.z = nb[b + 8] | (nb[b + 9] << 8) | (nb[b + 10] << 16) | (nb[b + 11] << 24);
+            o.w = nb[b + 12] | (nb[b + 13] << 8) | (nb[b + 14] << 16) | (nb[b + 15] << 24);
+            st_(st.qb, oq + 16u * w, o);
+        }
+    }
+    st_(st.tw, o16, make_double2(now, wake));
+    st_(st.tk, o16, make_uint4(tau, nbp, rvm, (uint32_t)last_abs | (dn << 31)));
+    publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl, (uint32_t)K);
+}
+
 template <int DT>
 int launch_rollout(const GwState& st, const GwDevConst& cst, int K, int Kp, const uint16_t* act, uint8_t* fb, void* stream, bool below_limits)
 {
     const unsigned blk = 64;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.fast_ticks;
+    static const bool event_loop = getenv("GW_ROLLOUT_EVENT_LOOP") != nullptr;          // A/B switch: the older form
+    if constexpr (DT > 0) {
+        if (!event_loop) {
+            if (fast && below_limits)
+                hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
+            else if (fast)
+                hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 1>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
+            else
+                hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 0>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
+            return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+        }
+    }
     if (fast && below_limits)
         hipLaunchKernelGGL((ct_rollout_sfx_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
     else if (fast)

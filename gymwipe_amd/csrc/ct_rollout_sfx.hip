@@ -1,6 +1,9 @@
 // ct_rollout_sfx.hip -- gw_rollout(): K consecutive env.step() calls from pre-staged actions in ONE
 // persistent launch, for the default (suffix) state layout.
 //
+// Two forms live here: the step-synchronous kernel (ct_rollout_sync_kernel, compile-time sender counts: what gw_rollout
+// launches since round 3, see its comment) and the event loop it replaced (ct_rollout_sfx_kernel: any sender count, and
+// GW_ROLLOUT_EVENT_LOOP=1), whose rationale follows.
 // Why a second kernel: with one launch per step every wave lasts as long as its slowest env (0..9
 // data transmissions per step, 1.6 on average), so ~80% of the lane-iterations of the window loop are
 // idle.  Here a lane is not tied to the step boundary of its neighbours: the loop body is ONE

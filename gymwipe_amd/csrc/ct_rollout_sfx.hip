@@ -538,10 +538,14 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
 // lazy exactly as above.  Same results bit for bit (the tests run both forms against the oracle; GW_ROLLOUT_EVENT_LOOP=1
 // selects the event loop).
 template <int DT, int MODE>
-__global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevConst c, int K, int Kp,
-                                                            const uint16_t* __restrict__ actions,
-                                                            uint8_t* __restrict__ feedback)
+__global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevConst c, int K,
+                                                            const int32_t* __restrict__ device, const int32_t* __restrict__ duration,
+                                                            int32_t* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done)
 {
+    // Actions and outputs in the C-ABI's own step-major layout ([K][N]: a step's row is coalesced across the wave's lanes), read
+    // and written by this kernel itself: step k + 1's action is loaded while step k is walked, a step's three outputs are
+    // stores nothing waits for.  (The event loop reads packed per-env action records and writes feedback bytes, with a
+    // transposing kernel on either side: 15 us per 64 steps x 65 536 envs, an eighth of this kernel's own time.)
     static_assert(DT > 0, "the any-D rollout keeps the event loop");
     constexpr int D = DT, R = D + 1, RRM = D;
     constexpr int NWC = (2 * DT + 1 + 15) / 16;
@@ -604,28 +608,24 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
 
     Tally kt = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, fl = 0;
-    uint32_t fbw = 0;
     int k = 0;
-    const uint16_t* act = actions + (size_t)e * Kp;
-    uint8_t* fbp = feedback + (size_t)e * Kp;
-    uint4 aw = ld<uint4>(act, 0);   // actions of steps 0..7
-
-    auto put_feedback = [&](uint32_t byte) {
-        fbw |= byte << ((k & 3) * 8);
-        if ((k & 3) == 3 || k == K - 1) { st_(fbp, (uint32_t)(k & ~3), fbw); fbw = 0; }
+    int d_next = device[e], du_next = duration[e];              // step 0's action
+    auto put_feedback = [&](int32_t latest, int32_t r) {
+        const size_t at = (size_t)k * N + e;
+        obs[at] = latest + c.counter_bound;
+        reward[at] = (float)r;
+        done[at] = (uint8_t)dn;
         k++;
-        if ((k & 7) == 0 && k < K) aw = ld<uint4>(act, (uint32_t)k * 2u);                // next 8 actions
     };
 
     while (k < K) {
-        // ---- start of step k (counter_traffic.py:146-158) ----
-        const uint32_t a = (word_of(aw, (k & 7) >> 1) >> ((k & 1) * 16)) & 0xffffu;
-        const int d = (int)(a & 0xffu);
-        const int du = (int)(a >> 8);
+        // ---- start of step k (counter_traffic.py:146-158); the next step's action is requested now ----
+        const int d = d_next, du = du_next;
+        if (k + 1 < K) { d_next = device[(size_t)(k + 1) * N + e]; du_next = duration[(size_t)(k + 1) * N + e]; }
         if ((unsigned)d >= (unsigned)D || (unsigned)du >= (unsigned)c.max_duration) {
             fl |= GW_FLAG_BADACT;                    // env untouched, feedback repeats the current values
             k_bad++;
-            put_feedback((uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | (10u << 2) | (dn << 7));
+            put_feedback(pv * ((int)(rvm & 1u) - (int)((rvm >> 1) & 1u)), 0);
             continue;
         }
         uint32_t l0 = 0, t0 = 0, s_d_old = 0, mult_d = 0, inv16_d = 65536u;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
         last_abs = abs_d;
         r = r > 10 ? 10 : (r < -10 ? -10 : r);
         now = t_end;
-        put_feedback((uint32_t)((int)(rvm & 1u) - (int)((rvm >> 1) & 1u) + 1) | ((uint32_t)(r + 10) << 2) | (dn << 7));
+        put_feedback(latest, r);
     }
 
     // ---- catch up: ticks up to the end of the last step, every queue to the final tick ----
@@ -850,24 +850,29 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
     publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl, (uint32_t)K);
 }
 
+// the step-synchronous form: the caller's step-major arrays directly (no packing / expanding launches)
+template <int DT>
+int launch_rollout_sync(const GwState& st, const GwDevConst& cst, int K, const int32_t* device, const int32_t* duration,
+                        int32_t* obs, float* reward, uint8_t* done, void* stream, bool below_limits)
+{
+    const unsigned blk = 64;
+    const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
+    const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.fast_ticks;
+    if (fast && below_limits)
+        hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, device, duration, obs, reward, done);
+    else if (fast)
+        hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 1>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, device, duration, obs, reward, done);
+    else
+        hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 0>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, device, duration, obs, reward, done);
+    return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
+}
+
 template <int DT>
 int launch_rollout(const GwState& st, const GwDevConst& cst, int K, int Kp, const uint16_t* act, uint8_t* fb, void* stream, bool below_limits)
 {
     const unsigned blk = 64;
     const unsigned grid = (unsigned)((st.N + blk - 1) / blk);
     const bool fast = cst.fast_fmod && cst.fast_div && cst.fast_decide && cst.fast_ticks;
-    static const bool event_loop = getenv("GW_ROLLOUT_EVENT_LOOP") != nullptr;          // A/B switch: the older form
-    if constexpr (DT > 0) {
-        if (!event_loop) {
-            if (fast && below_limits)
-                hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
-            else if (fast)
-                hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 1>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
-            else
-                hipLaunchKernelGGL((ct_rollout_sync_kernel<DT, 0>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
-            return hipGetLastError() == hipSuccess ? GW_OK : GW_EHIP;
-        }
-    }
     if (fast && below_limits)
         hipLaunchKernelGGL((ct_rollout_sfx_kernel<DT, 2>), dim3(grid), dim3(blk), 0, (hipStream_t)stream, st, cst, K, Kp, act, fb);
     else if (fast)
@@ -885,7 +890,21 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
                           bool below_limits)
 {
     const int Kp = (K + 15) / 16 * 16;
-    if (K <= 0 || Kp > k_cap || cst.max_duration > 0xfe) return GW_EUNSUPPORTED;
+    if (K <= 0 || Kp > k_cap) return GW_EUNSUPPORTED;
+    static const bool event_loop = getenv("GW_ROLLOUT_EVENT_LOOP") != nullptr;          // A/B switch: the older form
+    if (!event_loop) {
+        switch (st.D) {
+        case 2:  return launch_rollout_sync<2>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 3:  return launch_rollout_sync<3>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 4:  return launch_rollout_sync<4>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 6:  return launch_rollout_sync<6>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 8:  return launch_rollout_sync<8>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 16: return launch_rollout_sync<16>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 32: return launch_rollout_sync<32>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        default: break;                                  // any other D: the event loop below
+        }
+    }
+    if (cst.max_duration > 0xfe) return GW_EUNSUPPORTED;  // (the event loop's packed action records hold a byte of duration)
     const uint32_t N = (uint32_t)st.N;
     const unsigned g256 = (unsigned)((st.N + TP_ENVS - 1) / TP_ENVS);      // one block per 64-env tile
     hipLaunchKernelGGL(pack_actions_kernel, dim3(g256), dim3(256), 0, (hipStream_t)stream, N, K, Kp, device, duration, act_buf);

@@ -897,7 +897,9 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
         case 2:  return launch_rollout_sync<2>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 3:  return launch_rollout_sync<3>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 4:  return launch_rollout_sync<4>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 5:  return launch_rollout_sync<5>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 6:  return launch_rollout_sync<6>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
+        case 7:  return launch_rollout_sync<7>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 8:  return launch_rollout_sync<8>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 16: return launch_rollout_sync<16>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 32: return launch_rollout_sync<32>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);

@@ -835,7 +835,9 @@ int gw_launch_step_sfx(const GwState& st, const GwDevConst& cst, const int32_t* 
     case 2:  return launch<2>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
     case 3:  return launch<3>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
     case 4:  return launch<4>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 5:  return launch<5>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
     case 6:  return launch<6>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
+    case 7:  return launch<7>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
     case 8:  return launch<8>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
     case 16: return launch<16>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);
     case 32: return launch<32>(st, cst, device, duration, obs, reward, done, fb, stream, below_limits);

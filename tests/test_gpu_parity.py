@@ -62,9 +62,10 @@ def test_parity_with_resets(D, N, K, explicit):
     _run(env, orc, dev, dur, reset_every=32)
 
 
-@pytest.mark.parametrize("D", [3, 5, 8, 32])
+@pytest.mark.parametrize("D", [3, 5, 7, 8, 11, 32])
 def test_parity_other_device_counts(D):
-    """D = 3 (one-word record), 5 (generic in-memory path), 8 / 32 (multi-word records, max senders)."""
+    """D = 3 / 5 / 7 (one-word records), 8 / 32 (multi-word records, max senders), 11 (no instantiation of its own: the
+    any-D kernel with the record in memory)."""
     N, K = 512, 48
     env, orc = _mk(N, D)
     dev, dur = action_stream(200 + D, K, N, D)
@@ -222,7 +223,7 @@ def test_invalid_action_is_flagged_and_env_left_untouched():
 def test_fused_rollout_matches_oracle(D, N, K, monkeypatch):
     """gw_rollout: one persistent launch per <= 64 steps (free-running lanes, state in registers)
     must give exactly what K env.step() calls give -- outputs of every step and the final state.
-    Every sender count has a fused kernel (D = 5, 7, 11, 32: the any-D instantiation with per-lane arrays in LDS);
+    Every sender count has a fused kernel (D = 11: the any-D event loop with per-lane arrays in LDS);
     GW_ROLLOUT_STRICT makes gw_rollout fail rather than fall back to step launches, so this test cannot pass on a fallback."""
     import torch
     monkeypatch.setenv("GW_ROLLOUT_STRICT", "1")
@@ -363,7 +364,7 @@ def test_feedback_byte_codec_kernels():
         env.pack_feedback(obs, rew, done, check=True)
 
 
-@pytest.mark.parametrize("D,kw", [(4, {}), (16, {}), (5, {}), (4, {"explicit": True}), (4, {"per_env_geometry": True})])
+@pytest.mark.parametrize("D,kw", [(4, {}), (16, {}), (5, {}), (11, {}), (4, {"explicit": True}), (4, {"per_env_geometry": True})])
 def test_step_writes_its_feedback_byte_row(D, kw):
     """gw_step_fb (env.feedback_bytes_into): the step kernel stores the one-byte exchange form of its own feedback -- equal to
     what the packing kernel makes of (obs, reward, done), invalid actions included; the generic and live-PHY modes get there

@@ -1,9 +1,9 @@
 // ct_rollout_sfx.hip -- gw_rollout(): K consecutive env.step() calls from pre-staged actions in ONE
 // persistent launch, for the default (suffix) state layout.
 //
-// Two forms live here: the step-synchronous kernel (ct_rollout_sync_kernel, compile-time sender counts: what gw_rollout
-// launches since round 3, see its comment) and the event loop it replaced (ct_rollout_sfx_kernel: any sender count, and
-// GW_ROLLOUT_EVENT_LOOP=1), whose rationale follows.
+// Two forms live here: the step-synchronous kernel (ct_rollout_sync_kernel: what gw_rollout launches since round 3, see its
+// comment) and the event loop it replaced (ct_rollout_sfx_kernel with the packing / expanding kernels: GW_ROLLOUT_EVENT_LOOP=1,
+// the A/B reference, kept under test), whose rationale follows.
 // Why a second kernel: with one launch per step every wave lasts as long as its slowest env (0..9
 // data transmissions per step, 1.6 on average), so ~80% of the lane-iterations of the window loop are
 // idle.  Here a lane is not tied to the step boundary of its neighbours: the loop body is ONE
@@ -528,15 +528,15 @@ __global__ __launch_bounds__(256) void ct_rollout_sfx_kernel(GwState st, GwDevCo
     publish_env_counters(st.sa, N, e, kt.pop, kt.deliv, k_bad, fl, (uint32_t)K);
 }
 
-// ---- the step-synchronous form (compile-time sender counts) --------------------------------------------------------------
+// ---- the step-synchronous form (every sender count) --------------------------------------------------------------
 // The event loop above was built when a data packet cost as much as an announcement (one pass of a ~140-instruction body
 // either way) and letting lanes run ahead of each other evened the work out.  Since the window loop has a straight-line form
 // (ct_step_sfx.hip: ~45 instructions per packet, every per-packet decision settled for the step up front), a packet is a third
 // of an announcement, and the lock-step of whole steps costs less than the event loop's ~60 exec-mask regions per pass: here
 // every lane takes step k together -- announcement, window (straight line, general loop where that declines), feedback -- with
 // the env's state in registers across all K steps, queue lengths of the senders not addressed and the ticks behind a window
-// lazy exactly as above.  Same results bit for bit (the tests run both forms against the oracle; GW_ROLLOUT_EVENT_LOOP=1
-// selects the event loop).
+// lazy exactly as above; DT == 0 = any sender count, the per-lane arrays as LDS columns.  Same results bit for bit (the tests
+// run both forms against the oracle; GW_ROLLOUT_EVENT_LOOP=1 selects the event loop).
 template <int DT, int MODE>
 __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevConst c, int K,
                                                             const int32_t* __restrict__ device, const int32_t* __restrict__ duration,
@@ -546,17 +546,27 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
     // and written by this kernel itself: step k + 1's action is loaded while step k is walked, a step's three outputs are
     // stores nothing waits for.  (The event loop reads packed per-env action records and writes feedback bytes, with a
     // transposing kernel on either side: 15 us per 64 steps x 65 536 envs, an eighth of this kernel's own time.)
-    static_assert(DT > 0, "the any-D rollout keeps the event loop");
-    constexpr int D = DT, R = D + 1, RRM = D;
-    constexpr int NWC = (2 * DT + 1 + 15) / 16;
+    constexpr bool GEN = DT == 0;                        // any sender count: per-lane arrays in LDS columns (as in the event loop)
+    constexpr int DM = GEN ? GW_MAX_DEVICES : DT;        // capacity
+    constexpr int NWC = (2 * DM + 1 + 15) / 16;
     constexpr int S = GW_MAX_NSTATES;
+    const int D = GEN ? c.D : DT, R = D + 1, RRM = D;
     const uint32_t N = (uint32_t)st.N;
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
 
-    constexpr int TRANS_B = ((DT + 1) * (DT + 1) * S + 15) / 16 * 16;
+    constexpr int TRANS_B = ((DM + 1) * (DM + 1) * S + 15) / 16 * 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_trans[TRANS_B];
-    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DT * S];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DT * S];
+    __shared__ __attribute__((aligned(16))) double  s_ber[2 * DM * S];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cls[2 * DM * S];
+    __shared__ uint32_t s_cols[GEN ? (3 * DM + 1) * 64 : 1];     // GEN: len[D], tb[D], sta[R] columns per lane
+    __shared__ uint2 s_mi[GEN ? DM : 1];                 // GEN: {mult, ceil(65536/mult)} and terminal-state masks, indexed by
+    __shared__ uint32_t s_term[GEN ? DM : 1];            //      the lane's own addressed sender
+    if constexpr (GEN) {
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+            s_mi[i] = make_uint2((uint32_t)st.cst->mult[i], st.cst->inv16[i]);
+            s_term[i] = st.cst->term[i];
+        }
+    }
     {
         const int n_tr = (R * R * S + 15) >> 4, n_be = (2 * D * S * 8) >> 4, n_cl = (2 * D * S) >> 4;
         for (int i = threadIdx.x; i < n_tr; i += blockDim.x) *reinterpret_cast<uint4*>(s_trans + ((uint32_t)i << 4)) = ld<uint4>(st.trans, (uint32_t)i << 4);
@@ -567,12 +577,19 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
     if (e >= N) return;
 
     // ---- state -> registers ----
-    const uint32_t o16 = e << 4, oq = e * (16u * NWC);
+    const uint32_t RB = GEN ? (uint32_t)st.RB : 16u * NWC;
+    const uint32_t o16 = e << 4, oq = e * RB;
     const uint4 ip = ld<uint4>(st.ip, o16);
     const double2 tw = ld<double2>(st.tw, o16);
     const uint4 tk = ld<uint4>(st.tk, o16);
-    uint32_t len[DT], tb[DT], sta[DT + 1];
-    {
+    typename ArrSel<GEN, DM>::rw len, tb;
+    typename ArrSel<GEN, DM + 1>::rw sta;
+    if constexpr (GEN) {
+        uint32_t* col = s_cols + (threadIdx.x & 63);
+        len.p = col; tb.p = col + DM * 64; sta.p = col + 2 * DM * 64;
+        for (int i = 0; i < D; ++i) len[i] = st.qb[oq + (uint32_t)i];
+        for (int j = 0; j < R; ++j) sta[j] = st.qb[oq + (uint32_t)(D + j)];
+    } else {
         uint4 qw[NWC];
 #pragma unroll
         for (int w = 0; w < NWC; ++w) qw[w] = ld<uint4>(st.qb, oq + 16u * w);
@@ -600,11 +617,19 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
     const bool idem = c.idem_states != 0;
     const uint32_t bound = (uint32_t)c.counter_bound, base_bytes = (uint32_t)(c.mac_hdr + c.net_hdr);
     const int mh = c.mac_hdr, pv = c.payload_value;
-    uint32_t mult[DT], term[DT], inv16[DT];
+    uint32_t live_mask = 0u;                             // any-D kernel: bit i = sender i is in a non-terminal noise state
+    if constexpr (GEN) {
+        for (int i = 0; i < D; ++i) live_mask |= ((s_term[i] >> sta[i]) & 1u) ? 0u : (1u << i);
+    }
+    typename ArrSel<GEN, DM>::ro mult, term, inv16;
+    if constexpr (GEN) {
+        mult.p = st.cst->mult; mult.shift16 = 0; term.p = st.cst->term; term.shift16 = 1; inv16.p = st.cst->inv16; inv16.shift16 = 0;
+    } else {
 #pragma unroll
-    for (int i = 0; i < DT; ++i) { mult[i] = (uint32_t)c.mult[i]; term[i] = c.term[i]; inv16[i] = c.inv16[i]; }
+        for (int i = 0; i < DT; ++i) { mult.v[i] = (uint32_t)c.mult[i]; term.v[i] = c.term[i]; inv16.v[i] = c.inv16[i]; }
+    }
 #pragma unroll
-    for (int i = 0; i < DT; ++i) tb[i] = tau;
+    for (int i = 0; i < D; ++i) tb[i] = tau;
 
     Tally kt = {0, 0, 0, 0, 0};
     uint32_t k_bad = 0, fl = 0;
@@ -629,16 +654,25 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
             continue;
         }
         uint32_t l0 = 0, t0 = 0, s_d_old = 0, mult_d = 0, inv16_d = 65536u;
+        if constexpr (GEN) {
+            l0 = len[d]; t0 = tb[d]; s_d_old = sta[d];
+            mult_d = s_mi[d].x; inv16_d = s_mi[d].y;
+        } else {
 #pragma unroll
-        for (int i = 0; i < D; ++i)
-            if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = inv16[i]; s_d_old = sta[i]; }
+            for (int i = 0; i < D; ++i)
+                if (i == d) { l0 = len[i]; t0 = tb[i]; mult_d = mult[i]; inv16_d = inv16[i]; s_d_old = sta[i]; }
+        }
         uint32_t len_d = gw_len_after_ticks(l0, tau - t0, mult_d, kt);          // the addressed queue, up to date
         const int slots = du * c.duration_factor;                               // counter_traffic.py:149
         const int Ld = ndigits(slots);
         const bool cls_valid = NOLIM || now < c.cls_limit;
         const uint32_t s_d = s_trans[(uint32_t)((d * R + RRM) * S) + s_d_old];  // d after hearing the RRM
 #pragma unroll
-        for (int i = 0; i < D; ++i) if (i == d) sta[i] = s_d;
+        for (int i = 0; i < (GEN ? 0 : D); ++i) if (i == d) sta[i] = s_d;
+        if constexpr (GEN) {
+            sta[d] = s_d;
+            live_mask = ((s_term[d] >> s_d) & 1u) ? (live_mask & ~(1u << d)) : (live_mask | (1u << d));
+        }
         // ---- A.1 / A.2: announcement ----
         const TxTimes an = tx_times(m, now, hd, m.over_rate((double)(Ld * 8)));
         kt.tx++;
@@ -790,11 +824,16 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
             }
         }
         bool all_term = true;
+        if constexpr (GEN) {
+            all_term = (live_mask & ~(1u << d)) == 0u;
+            len[d] = len_d; tb[d] = tau;
+        } else {
 #pragma unroll
-        for (int i = 0; i < D; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
+            for (int i = 0; i < D; ++i) all_term = all_term && (i == d || ((term[i] >> sta[i]) & 1u));
 #pragma unroll
-        for (int i = 0; i < D; ++i)
-            if (i == d) { len[i] = len_d; tb[i] = tau; }
+            for (int i = 0; i < D; ++i)
+                if (i == d) { len[i] = len_d; tb[i] = tau; }
+        }
         if (!all_term) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
@@ -806,6 +845,7 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
                     si = s2;
                 }
                 sta[i] = si;
+                if constexpr (GEN) live_mask = ((term[i] >> si) & 1u) ? (live_mask & ~(1u << i)) : (live_mask | (1u << i));
             }
         }
         sta[RRM] = s_r;
@@ -826,7 +866,10 @@ __global__ __launch_bounds__(64) void ct_rollout_sync_kernel(GwState st, GwDevCo
 #pragma unroll
         for (int i = 0; i < D; ++i) len[i] = gw_len_after_ticks(len[i], tau - tb[i], mult[i], kt);
     }
-    {
+    if constexpr (GEN) {
+        for (int i = 0; i < D; ++i) st.qb[oq + (uint32_t)i] = (uint8_t)len[i];
+        for (int j = 0; j < R; ++j) st.qb[oq + (uint32_t)(D + j)] = (uint8_t)sta[j];
+    } else {
         uint32_t nb[16 * NWC];
 #pragma unroll
         for (int b = 0; b < 16 * NWC; ++b) nb[b] = 0u;
@@ -891,7 +934,8 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
 {
     const int Kp = (K + 15) / 16 * 16;
     if (K <= 0 || Kp > k_cap) return GW_EUNSUPPORTED;
-    static const bool event_loop = getenv("GW_ROLLOUT_EVENT_LOOP") != nullptr;          // A/B switch: the older form
+    // A/B switch: the older form -- for handles created while the switch was set (they have its scratch records)
+    const bool event_loop = getenv("GW_ROLLOUT_EVENT_LOOP") != nullptr && act_buf != nullptr && fb_buf != nullptr;
     if (!event_loop) {
         switch (st.D) {
         case 2:  return launch_rollout_sync<2>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
@@ -903,7 +947,7 @@ int gw_launch_rollout_sfx(const GwState& st, const GwDevConst& cst, int K, const
         case 8:  return launch_rollout_sync<8>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 16: return launch_rollout_sync<16>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
         case 32: return launch_rollout_sync<32>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);
-        default: break;                                  // any other D: the event loop below
+        default: return launch_rollout_sync<0>(st, cst, K, device, duration, obs, reward, done, stream, below_limits);   // any other D: per-lane arrays in LDS
         }
     }
     if (cst.max_duration > 0xfe) return GW_EUNSUPPORTED;  // (the event loop's packed action records hold a byte of duration)

@@ -447,7 +447,9 @@ int gw_create(const gw_config* cfg, gw_env** out)
             int cap = rc_env ? atoi(rc_env) : 64;
             if (cap < 0) cap = 0;
             st.rcap = (cap + 15) / 16 * 16;
-            if (st.rcap > 0) { TRY_ALLOC(st.ract, N * st.rcap);  TRY_ALLOC(st.rfb, N * st.rcap); }
+            // (scratch of the event-loop form only -- packed action / feedback records, 3 bytes per env and step of a chunk: an A/B
+            //  switch since the step-synchronous kernel reads and writes the caller's arrays; the switch is read here)
+            if (st.rcap > 0 && getenv("GW_ROLLOUT_EVENT_LOOP")) { TRY_ALLOC(st.ract, N * st.rcap);  TRY_ALLOC(st.rfb, N * st.rcap); }
         }
     }
     double *d_prx = nullptr, *d_pos = nullptr, *d_extra = nullptr;

@@ -223,7 +223,7 @@ def test_invalid_action_is_flagged_and_env_left_untouched():
 def test_fused_rollout_matches_oracle(D, N, K, monkeypatch):
     """gw_rollout: one persistent launch per <= 64 steps (free-running lanes, state in registers)
     must give exactly what K env.step() calls give -- outputs of every step and the final state.
-    Every sender count has a fused kernel (D = 11: the any-D event loop with per-lane arrays in LDS);
+    Every sender count has a fused kernel (D = 11: the any-D instantiation with per-lane arrays in LDS);
     GW_ROLLOUT_STRICT makes gw_rollout fail rather than fall back to step launches, so this test cannot pass on a fallback."""
     import torch
     monkeypatch.setenv("GW_ROLLOUT_STRICT", "1")
@@ -246,6 +246,26 @@ def test_fused_rollout_matches_oracle(D, N, K, monkeypatch):
         oo, orr, od = orc.step(dev2[k], dur2[k])
         assert (o.cpu().numpy() == oo).all() and (r.cpu().numpy() == orr).all()
     assert_state_equal(env, orc, STATE_FIELDS, where="after rollout + steps")
+
+
+@pytest.mark.parametrize("D,N,K", [(4, 1024, 70), (16, 256, 48), (11, 129, 64)])
+def test_fused_rollout_event_loop_form_still_matches(D, N, K, monkeypatch):
+    """GW_ROLLOUT_EVENT_LOOP=1 (read at gw_create and at gw_rollout): the rounds-1/2 form of the fused rollout -- an event loop
+    over packed action / feedback records with a transposing launch on either side -- kept as the A/B reference of the
+    step-synchronous kernel.  Same outputs, same final state."""
+    import torch
+    monkeypatch.setenv("GW_ROLLOUT_STRICT", "1")
+    monkeypatch.setenv("GW_ROLLOUT_EVENT_LOOP", "1")
+    env, orc = _mk(N, D)
+    dev, dur = action_stream(1300 + D + K, K, N, D)
+    assert (env.reset().cpu().numpy() == orc.reset()).all()
+    obs, rew, done = env.rollout(torch.from_numpy(dev), torch.from_numpy(dur))
+    obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    for k in range(K):
+        oo, orr, od = orc.step(dev[k], dur[k])
+        assert (obs[k] == oo).all() and (rew[k] == orr).all() and (done[k] == od).all(), k
+    assert_state_equal(env, orc, STATE_FIELDS + STAT_FIELDS, where="after the event-loop rollout")
+    env.check()
 
 
 def test_fused_rollout_with_invalid_actions():
